@@ -1,0 +1,268 @@
+"""ctypes front-end of the CPU oracle (oracle/pbbi_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of pbbi_oracle.c.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product package never does.  Parity pinning: PINNED against the reference's own
+outputs (tests/golden/*.npz, tests/test_oracle_golden.py).
+
+Potentials are described by plain dicts (`pot_*` helpers below) so that the
+tests can hand the *same* parameters to the oracle and to the product's
+descriptors.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+HARMONIC, GAUSS_DIAG, GAUSS_DENSE, ROSENBROCK = 0, 1, 2, 3
+LEAPFROG, STORMER_VERLET = 0, 1
+COMPAT_P_FROM_OLDQ = 1
+STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
+METHODS = {"Leapfrog": LEAPFROG, "Stormer-Verlet": STORMER_VERLET}
+
+
+class _Pot(C.Structure):
+    _fields_ = [("kind", C.c_int), ("D", C.c_int), ("mean", C.c_void_p), ("prec", C.c_void_p),
+                ("cst", C.c_double), ("a", C.c_double), ("b", C.c_double), ("s", C.c_double)]
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc, a few seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "pbbi_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.oracle_get_max_threads.restype = C.c_int
+    return _LIB
+
+
+def set_threads(n):
+    lib().oracle_set_threads(C.c_int(int(n)))
+
+
+def max_threads():
+    return int(lib().oracle_get_max_threads())
+
+
+# ------------------------------------------------------------------ potentials
+def pot_harmonic(springConsts):
+    return dict(kind=HARMONIC, prec=np.ascontiguousarray(springConsts, dtype=np.float64))
+
+
+def pot_gauss_diag(mean, prec, const=0.0):
+    return dict(kind=GAUSS_DIAG, mean=np.ascontiguousarray(mean, dtype=np.float64),
+                prec=np.ascontiguousarray(prec, dtype=np.float64), cst=float(const))
+
+
+def pot_gauss_dense(mean, precision, const=0.0):
+    P = np.ascontiguousarray(precision, dtype=np.float64)
+    assert P.ndim == 2 and P.shape[0] == P.shape[1]
+    return dict(kind=GAUSS_DENSE, mean=np.ascontiguousarray(mean, dtype=np.float64), prec=P,
+                cst=float(const), D=P.shape[0])
+
+
+def pot_rosenbrock(D, a=1.0, b=100.0, s=20.0):
+    return dict(kind=ROSENBROCK, D=int(D), a=float(a), b=float(b), s=float(s))
+
+
+def _cpot(pot):
+    D = pot.get("D")
+    if D is None:
+        D = int(pot["prec"].shape[0])
+    keep = []
+    mean = pot.get("mean")
+    prec = pot.get("prec")
+    for arr in (mean, prec):
+        if arr is not None:
+            assert arr.dtype == np.float64 and arr.flags.c_contiguous
+            keep.append(arr)
+    st = _Pot(pot["kind"], int(D),
+              mean.ctypes.data if mean is not None else None,
+              prec.ctypes.data if prec is not None else None,
+              pot.get("cst", 0.0), pot.get("a", 1.0), pot.get("b", 100.0), pot.get("s", 20.0))
+    return st, keep, int(D)
+
+
+def _dn(arr):
+    assert arr.dtype == np.float64 and arr.ndim == 2 and arr.flags.c_contiguous, \
+        "oracle arrays are (D, N) C-order float64"
+    return arr.shape
+
+
+def _ptr(arr):
+    return None if arr is None else C.c_void_p(arr.ctypes.data)
+
+
+def _mass(mass, N):
+    if mass is None:
+        return None
+    m = np.ascontiguousarray(mass, dtype=np.float64)
+    assert m.shape == (N,)
+    return m
+
+
+# ------------------------------------------------------------------ entry points
+def potential(pot, q, want_grad=False):
+    st, keep, D = _cpot(pot)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    single = q.ndim == 1
+    q2 = q.reshape(D, -1) if single else q
+    assert q2.shape[0] == D
+    N = q2.shape[1]
+    q2 = np.ascontiguousarray(q2)
+    U = np.empty(N)
+    g = np.empty_like(q2) if want_grad else None
+    rc = lib().oracle_potential(C.byref(st), _ptr(q2), C.c_int64(N), C.c_int64(N), _ptr(U), _ptr(g))
+    assert rc == 0
+    if single:
+        return (U[0], g[:, 0]) if want_grad else U[0]
+    return (U, g) if want_grad else U
+
+
+def integrate(pot, method, q, p, mass, h, L):
+    """In-place integrate() on (D, N) arrays; returns v (Integrator.v)."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert (Dq, N) == _dn(p) and Dq == D
+    m = _mass(mass, N)
+    v = np.empty_like(q)
+    rc = lib().oracle_integrate(C.byref(st), C.c_int(METHODS.get(method, method)), _ptr(q), _ptr(p),
+                                _ptr(m), C.c_int64(N), C.c_int64(N), C.c_double(h), C.c_int(L),
+                                _ptr(v))
+    assert rc == 0
+    return v
+
+
+def weights(pot, q, p, mass=None):
+    st, keep, D = _cpot(pot)
+    _, N = _dn(q)
+    m = _mass(mass, N)
+    w, H = np.empty(N), np.empty(N)
+    rc = lib().oracle_weights(C.byref(st), _ptr(q), _ptr(p), _ptr(m), C.c_int64(N), C.c_int64(N),
+                              _ptr(w), _ptr(H))
+    assert rc == 0
+    return w, H
+
+
+def weights_ratio(pot, newQ, newP, oldQ, oldP, mass=None):
+    st, keep, D = _cpot(pot)
+    _, N = _dn(newQ)
+    m = _mass(mass, N)
+    r = np.empty(N)
+    with np.errstate(all="ignore"):
+        rc = lib().oracle_weights_ratio(C.byref(st), _ptr(newQ), _ptr(newP), _ptr(oldQ), _ptr(oldP),
+                                        _ptr(m), C.c_int64(N), C.c_int64(N), _ptr(r))
+    assert rc == 0
+    return r
+
+
+def hmc_iter(pot, method, q, p, u, mass, h, L, compat=COMPAT_P_FROM_OLDQ):
+    """One getSamples iteration, in place on q (state) and p (drawn momentum).
+    Returns (ratio, reject_mask)."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert _dn(p) == (Dq, N) and Dq == D
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    assert u.shape == (N,)
+    m = _mass(mass, N)
+    ratio = np.empty(N)
+    rej = np.empty(N, dtype=np.uint8)
+    rc = lib().oracle_hmc_iter(C.byref(st), C.c_int(METHODS.get(method, method)), _ptr(q), _ptr(p),
+                               _ptr(u), _ptr(m), C.c_int64(N), C.c_int64(N), C.c_double(h),
+                               C.c_int(L), C.c_int(compat), _ptr(ratio), _ptr(rej))
+    assert rc == 0
+    return ratio, rej.astype(bool)
+
+
+def philox_raw(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().oracle_philox_raw(c, k, o)
+    return [int(x) for x in o]
+
+
+def philox_normal(seed, stream, it, chain0, D, N, scale=1.0):
+    out = np.empty((D, N))
+    sc = None
+    s0 = 1.0
+    if np.ndim(scale) == 0:
+        s0 = float(scale)
+    else:
+        sc = np.ascontiguousarray(scale, dtype=np.float64)
+        assert sc.shape == (N,)
+    lib().oracle_philox_normal(C.c_uint64(seed), C.c_int(stream), C.c_uint64(it), C.c_uint64(chain0),
+                               C.c_int(D), C.c_int64(N), C.c_int64(N), C.c_double(s0), _ptr(sc),
+                               _ptr(out))
+    return out
+
+
+def philox_uniform(seed, it, chain0, N):
+    out = np.empty(N)
+    lib().oracle_philox_uniform(C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0), C.c_int64(N),
+                                _ptr(out))
+    return out
+
+
+def hmc_run_philox(pot, method, q, mass, h, L, S, seed, iter0=0, chain0=0, kT=1.0,
+                   compat=COMPAT_P_FROM_OLDQ, want_momenta=True):
+    """S iterations with the Philox contract.  q (D,N) is the state, updated in
+    place.  Returns samples (S,D,N), momenta (S,D,N)|None, reject (S,N) bool,
+    ratio (S,N)."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert Dq == D
+    m = _mass(mass, N)
+    samples = np.empty((S, D, N))
+    momenta = np.empty((S, D, N)) if want_momenta else None
+    rej = np.empty((S, N), dtype=np.uint8)
+    ratio = np.empty((S, N))
+    rc = lib().oracle_hmc_run_philox(C.byref(st), C.c_int(METHODS.get(method, method)), _ptr(q),
+                                     _ptr(m), C.c_int64(N), C.c_int64(N), C.c_double(h), C.c_int(L),
+                                     C.c_int(S), C.c_int(compat), C.c_uint64(seed),
+                                     C.c_uint64(iter0), C.c_uint64(chain0), C.c_double(kT),
+                                     _ptr(samples), _ptr(momenta), _ptr(rej), _ptr(ratio))
+    assert rc == 0
+    return samples, momenta, rej.astype(bool), ratio
+
+
+def get_samples_numpy_stream(pot, method, D, N, S, simulTime, stepSize, temperature, qStd, seed,
+                             mass=None, compat=COMPAT_P_FROM_OLDQ):
+    """Restatement of HMC.getSamples (src/HMC.py:123-183) on the legacy NumPy
+    RandomState stream: q0 = normals*qStd, then per iteration D*N normals times
+    sqrt(mass*kB*T) and N uniforms (src/ensemble.py:72-74,88-91).
+    Returns dict with samples/momenta as (D,N,S) like the reference."""
+    from scipy.constants import k as kB
+    rs = np.random.RandomState(seed)
+    L = int(simulTime / stepSize)  # src/integrator.py:51
+    m = np.ones(N) if mass is None else np.asarray(mass, float)
+    q = np.ascontiguousarray(rs.standard_normal((D, N)) * qStd)
+    pStd = np.sqrt(m * kB * temperature)
+    samples = np.zeros((D, N, S))
+    momenta = np.zeros((D, N, S))
+    ratios, masks = [], []
+    for i in range(S):
+        p = np.ascontiguousarray(rs.standard_normal((D, N)) * pStd)
+        u = rs.uniform(size=N)
+        r, rej = hmc_iter(pot, method, q, p, u, m, stepSize, L, compat)
+        samples[:, :, i] = q
+        momenta[:, :, i] = p
+        ratios.append(r)
+        masks.append(rej)
+    return dict(samples=samples, momenta=momenta, ratio=np.stack(ratios),
+                reject_mask=np.stack(masks), numSteps=L)

@@ -1,0 +1,491 @@
+/*
+ * pbbi_oracle.c -- CPU restatement of the reference's ensemble-HMC hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker* for the HIP path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (physicsbasedbayesianinference_amd/) never imports, links or
+ * executes anything under oracle/.
+ *
+ * Parity pinning: PINNED.  Every function below is checked in
+ * tests/test_oracle_golden.py against golden vectors produced by running the
+ * reference's own unmodified Python (tests/golden/gen_golden.py) on identical
+ * seeds: trajectories <= 1e-12 relative, reject masks equal.
+ *
+ * Each function cites the reference file:line (relative to /root/reference)
+ * whose operation ORDER it follows: per-chain outer loop, sequential dot
+ * products, no FMA contraction (build with -ffp-contract=off).
+ *
+ * Layout: all state arrays are (D, N) C-order with leading stride ldn >= N,
+ * i.e. element (d, n) at [d*ldn + n] -- chain index fastest, exactly the
+ * reference's np.zeros((numDimensions, numParticles)) (src/ensemble.py:40-41).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_MAXD 8192
+
+enum { POT_HARMONIC = 0, POT_GAUSS_DIAG = 1, POT_GAUSS_DENSE = 2, POT_ROSENBROCK = 3 };
+enum { METHOD_LEAPFROG = 0, METHOD_STORMER_VERLET = 1 };
+/* compat flag bit 0: reproduce src/HMC.py:176 (rejected momentum <- oldQ) */
+enum { COMPAT_P_FROM_OLDQ = 1 };
+
+typedef struct {
+    int kind;
+    int D;
+    const double* mean; /* D entries, or NULL (= 0)                         */
+    const double* prec; /* harmonic: spring consts (D); diag: precisions (D);
+                           dense: D x D row-major precision matrix           */
+    double cst;         /* additive constant of U                            */
+    double a, b, s;     /* Rosenbrock parameters                             */
+} oracle_pot;
+
+int oracle_version(void) { return 1; }
+
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int oracle_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* --------------------------------------------------------------- potentials
+ * U(q) and grad U(q) for ONE chain; q, g are contiguous (D,) vectors.
+ * These restate the closed-form NumPy callables the golden generator hands to
+ * the reference (tests/golden/gen_golden.py), which in turn stand in for
+ *   - harmonicPotentialND                     src/potential.py:18-27
+ *   - -multivariate_normal.logpdf(q, mu, cov) src/tests/test_HMC.py:49,125
+ *   - Rosenbrock: defined by the build (last row).
+ */
+static double pot_U(const oracle_pot* P, const double* q) {
+    const int D = P->D;
+    double acc = 0.0;
+    switch (P->kind) {
+    case POT_HARMONIC: /* 0.5 * dot(k, q**2)  (src/potential.py:27) */
+        for (int d = 0; d < D; ++d) acc += P->prec[d] * (q[d] * q[d]);
+        return 0.5 * acc + P->cst;
+    case POT_GAUSS_DIAG: /* 0.5 * dot(prec*x, x) + c */
+        for (int d = 0; d < D; ++d) {
+            const double x = q[d] - (P->mean ? P->mean[d] : 0.0);
+            acc += (P->prec[d] * x) * x;
+        }
+        return 0.5 * acc + P->cst;
+    case POT_GAUSS_DENSE: { /* 0.5 * dot(x, P @ x) + c */
+        for (int i = 0; i < D; ++i) {
+            double gi = 0.0;
+            for (int j = 0; j < D; ++j)
+                gi += P->prec[(size_t)i * D + j] * (q[j] - (P->mean ? P->mean[j] : 0.0));
+            acc += (q[i] - (P->mean ? P->mean[i] : 0.0)) * gi;
+        }
+        return 0.5 * acc + P->cst;
+    }
+    case POT_ROSENBROCK: { /* (sum b*t^2 + sum (a-q_i)^2) / s, t = q_{i+1}-q_i^2 */
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i + 1 < D; ++i) {
+            const double t = q[i + 1] - q[i] * q[i];
+            s1 += (P->b * t) * t;
+        }
+        for (int i = 0; i + 1 < D; ++i) {
+            const double r = P->a - q[i];
+            s2 += r * r;
+        }
+        return (s1 + s2) / P->s + P->cst;
+    }
+    }
+    return NAN;
+}
+
+static void pot_grad(const oracle_pot* P, const double* q, double* g) {
+    const int D = P->D;
+    switch (P->kind) {
+    case POT_HARMONIC:
+        for (int d = 0; d < D; ++d) g[d] = P->prec[d] * q[d];
+        return;
+    case POT_GAUSS_DIAG:
+        for (int d = 0; d < D; ++d) g[d] = P->prec[d] * (q[d] - (P->mean ? P->mean[d] : 0.0));
+        return;
+    case POT_GAUSS_DENSE:
+        for (int i = 0; i < D; ++i) {
+            double gi = 0.0;
+            for (int j = 0; j < D; ++j)
+                gi += P->prec[(size_t)i * D + j] * (q[j] - (P->mean ? P->mean[j] : 0.0));
+            g[i] = gi;
+        }
+        return;
+    case POT_ROSENBROCK:
+        for (int d = 0; d < D; ++d) g[d] = 0.0;
+        for (int i = 0; i + 1 < D; ++i) {
+            const double t = q[i + 1] - q[i] * q[i];
+            g[i] += (((-4.0 * P->b) * q[i]) * t - 2.0 * (P->a - q[i])) / P->s;
+            g[i + 1] += ((2.0 * P->b) * t) / P->s;
+        }
+        return;
+    }
+}
+
+/* gather / scatter one chain's column */
+static void col_get(const double* A, int D, int64_t ldn, int64_t n, double* x) {
+    for (int d = 0; d < D; ++d) x[d] = A[(size_t)d * ldn + n];
+}
+static void col_put(double* A, int D, int64_t ldn, int64_t n, const double* x) {
+    for (int d = 0; d < D; ++d) A[(size_t)d * ldn + n] = x[d];
+}
+
+/* potential(q) for all chains; grad_out may be NULL.  Mirrors calling the
+ * reference's potential / gradient callables column by column. */
+int oracle_potential(const oracle_pot* P, const double* q, int64_t N, int64_t ldn,
+                     double* U_out, double* grad_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD) return -1;
+#pragma omp parallel
+    {
+        double* x = (double*)malloc(sizeof(double) * 2 * D);
+        double* g = x + D;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            col_get(q, D, ldn, n, x);
+            if (U_out) U_out[n] = pot_U(P, x);
+            if (grad_out) {
+                pot_grad(P, x, g);
+                col_put(grad_out, D, ldn, n, g);
+            }
+        }
+        free(x);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- integrators
+ * getAccel(i) = -gradient(q[:, i]) / mass[i]            src/integrator.py:61-73
+ */
+static void accel(const oracle_pot* P, const double* q, double m, double* a, double* tmp) {
+    pot_grad(P, q, tmp);
+    for (int d = 0; d < P->D; ++d) a[d] = -tmp[d] / m;
+}
+
+/* One chain of Leapfrog.integrate                        src/integrator.py:105-120
+ *   v = p/m; a = getAccel
+ *   repeat L: q += (v*h + (0.5*a)*(h**2)); a' = getAccel; v += (0.5*(a+a'))*h; a = a'
+ *   p = v*m
+ */
+static void leapfrog_chain(const oracle_pot* P, double* q, double* p, double* v, double m,
+                           double h, int L, double* a, double* an, double* tmp) {
+    const int D = P->D;
+    const double h2 = h * h; /* self.stepSize**2 */
+    for (int d = 0; d < D; ++d) v[d] = p[d] / m;
+    accel(P, q, m, a, tmp);
+    for (int j = 0; j < L; ++j) {
+        for (int d = 0; d < D; ++d) q[d] += (v[d] * h + (0.5 * a[d]) * h2);
+        accel(P, q, m, an, tmp);
+        for (int d = 0; d < D; ++d) v[d] += (0.5 * (a[d] + an[d])) * h;
+        for (int d = 0; d < D; ++d) a[d] = an[d];
+    }
+    for (int d = 0; d < D; ++d) p[d] = v[d] * m;
+}
+
+/* One chain of StormerVerlet.integrate                   src/integrator.py:142-163
+ *   v = p/m; qPast = q; q = q + v*h + (0.5*a(q))*h**2
+ *   repeat L: tmp = q; q = 2*q - qPast + a(q)*h**2; qPast = tmp
+ *   v = (q - qPast)/h; p = v*m        (L+1 position steps, backward-difference v)
+ */
+static void stormer_verlet_chain(const oracle_pot* P, double* q, double* p, double* v, double m,
+                                 double h, int L, double* a, double* qpast, double* tmp) {
+    const int D = P->D;
+    const double h2 = h * h;
+    for (int d = 0; d < D; ++d) v[d] = p[d] / m;
+    for (int d = 0; d < D; ++d) qpast[d] = q[d];
+    accel(P, q, m, a, tmp);
+    for (int d = 0; d < D; ++d) q[d] = (q[d] + v[d] * h) + (0.5 * a[d]) * h2;
+    for (int j = 0; j < L; ++j) {
+        accel(P, q, m, a, tmp);
+        for (int d = 0; d < D; ++d) {
+            const double cur = q[d];
+            q[d] = (2 * cur - qpast[d]) + a[d] * h2;
+            qpast[d] = cur;
+        }
+    }
+    for (int d = 0; d < D; ++d) v[d] = (q[d] - qpast[d]) / h;
+    for (int d = 0; d < D; ++d) p[d] = v[d] * m;
+}
+
+/* integrate() over the whole ensemble, in place.  v_out (D,N) optional
+ * (Integrator.v, src/integrator.py:45).  mass NULL = ones. */
+int oracle_integrate(const oracle_pot* P, int method, double* q, double* p, const double* mass,
+                     int64_t N, int64_t ldn, double h, int L, double* v_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD || L < 0) return -1;
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 6 * D);
+        double *qc = buf, *pc = buf + D, *vc = buf + 2 * D, *a = buf + 3 * D, *b = buf + 4 * D,
+               *tmp = buf + 5 * D;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const double m = mass ? mass[n] : 1.0;
+            col_get(q, D, ldn, n, qc);
+            col_get(p, D, ldn, n, pc);
+            if (method == METHOD_LEAPFROG)
+                leapfrog_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
+            else
+                stormer_verlet_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
+            col_put(q, D, ldn, n, qc);
+            col_put(p, D, ldn, n, pc);
+            if (v_out) col_put(v_out, D, ldn, n, vc);
+        }
+        free(buf);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ energies
+ * H = 0.5*dot(p,p)/mass[i] + potential(q[:,i])            src/HMC.py:100-102
+ */
+static double hamiltonian(const oracle_pot* P, const double* q, const double* p, double m) {
+    double pp = 0.0;
+    for (int d = 0; d < P->D; ++d) pp += p[d] * p[d];
+    return 0.5 * pp / m + pot_U(P, q);
+}
+
+/* HMC.getWeights: exp(-H) per chain                      src/HMC.py:86-104
+ * H_out optional. */
+int oracle_weights(const oracle_pot* P, const double* q, const double* p, const double* mass,
+                   int64_t N, int64_t ldn, double* w_out, double* H_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD) return -1;
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 2 * D);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            col_get(q, D, ldn, n, buf);
+            col_get(p, D, ldn, n, buf + D);
+            const double H = hamiltonian(P, buf, buf + D, mass ? mass[n] : 1.0);
+            if (H_out) H_out[n] = H;
+            if (w_out) w_out[n] = exp(-H);
+        }
+        free(buf);
+    }
+    return 0;
+}
+
+/* HMC.getWeightsRatio: exp(oldH - newH) per chain        src/HMC.py:106-116 */
+int oracle_weights_ratio(const oracle_pot* P, const double* newQ, const double* newP,
+                         const double* oldQ, const double* oldP, const double* mass, int64_t N,
+                         int64_t ldn, double* ratio_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD) return -1;
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 2 * D);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const double m = mass ? mass[n] : 1.0;
+            col_get(oldQ, D, ldn, n, buf);
+            col_get(oldP, D, ldn, n, buf + D);
+            const double oldH = hamiltonian(P, buf, buf + D, m);
+            col_get(newQ, D, ldn, n, buf);
+            col_get(newP, D, ldn, n, buf + D);
+            const double newH = hamiltonian(P, buf, buf + D, m);
+            ratio_out[n] = exp(oldH - newH);
+        }
+        free(buf);
+    }
+    return 0;
+}
+
+/* One iteration of the HMC.getSamples loop body           src/HMC.py:154-179
+ *   in : q (state, D x N), p (freshly drawn momentum), u (N uniforms)
+ *   out: q, p overwritten with what the reference stores into samples_hmc[:,:,i]
+ *        and momentum_hmc[:,:,i]; ratio_out (N) and reject_out (N bytes) optional.
+ * Semantics restated:
+ *   - p = -p only feeds the (p-symmetric) energy; stored momentum is un-negated (:164,:179)
+ *   - mask = u > min(1, ratio) is the REJECT mask; NaN ratio => comparison False
+ *     => proposal accepted (:168-173)
+ *   - rejected: q <- oldQ (:175) and p <- oldQ (:176, reference bug) when
+ *     compat & COMPAT_P_FROM_OLDQ, else p <- oldP.
+ */
+int oracle_hmc_iter(const oracle_pot* P, int method, double* q, double* p, const double* u,
+                    const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
+                    double* ratio_out, unsigned char* reject_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD || L < 0) return -1;
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 8 * D);
+        double *qc = buf, *pc = buf + D, *vc = buf + 2 * D, *a = buf + 3 * D, *b = buf + 4 * D,
+               *tmp = buf + 5 * D, *oq = buf + 6 * D, *op = buf + 7 * D;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const double m = mass ? mass[n] : 1.0;
+            col_get(q, D, ldn, n, qc);
+            col_get(p, D, ldn, n, pc);
+            memcpy(oq, qc, sizeof(double) * D); /* oldQ = np.copy(q)  :156 */
+            memcpy(op, pc, sizeof(double) * D); /* oldP = np.copy(p)  :157 */
+            if (method == METHOD_LEAPFROG)
+                leapfrog_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
+            else
+                stormer_verlet_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
+            for (int d = 0; d < D; ++d) tmp[d] = -pc[d]; /* p = -p  :164 */
+            const double oldH = hamiltonian(P, oq, op, m);
+            const double newH = hamiltonian(P, qc, tmp, m);
+            const double ratio = exp(oldH - newH);                 /* :115 */
+            const double acc = (1.0 < ratio || ratio != ratio) ? ((ratio != ratio) ? ratio : 1.0)
+                                                               : ratio; /* np.minimum(1, ratio) */
+            const int reject = (u[n] > acc); /* False when acc is NaN  :173 */
+            if (reject) {
+                col_put(q, D, ldn, n, oq);
+                col_put(p, D, ldn, n, (compat & COMPAT_P_FROM_OLDQ) ? oq : op);
+            } else {
+                col_put(q, D, ldn, n, qc);
+                col_put(p, D, ldn, n, pc);
+            }
+            if (ratio_out) ratio_out[n] = ratio;
+            if (reject_out) reject_out[n] = (unsigned char)reject;
+        }
+        free(buf);
+    }
+    return 0;
+}
+
+/* ----------------------------------------------------------------- Philox RNG
+ * Counter-based generator of the device ("philox") mode; the product's HIP
+ * kernels implement the same contract (include/pbbi.h, "RNG contract").
+ * Philox-4x32-10 (Salmon et al., SC'11; Random123 constants).  This is the
+ * build's own design, not a reference feature: the reference only has the
+ * global NumPy RandomState (src/ensemble.py:72-74,88-91).
+ */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void oracle_philox_raw(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    philox4x32_10(ctr, key, out);
+}
+
+enum { STREAM_MOMENTUM = 0, STREAM_POSITION = 1, STREAM_UNIFORM = 2 };
+
+static void rng_block(uint64_t seed, uint32_t stream, uint64_t iter, uint64_t chain, uint32_t blk,
+                      uint32_t out[4]) {
+    const uint32_t ctr[4] = {(uint32_t)chain, blk, (uint32_t)iter,
+                             (stream & 0xFFu) | ((uint32_t)(chain >> 32) << 8)};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    philox4x32_10(ctr, key, out);
+}
+
+static double u53(uint32_t lo, uint32_t hi) { /* [0,1) with 53 random bits */
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53;
+}
+
+/* sin(pi x), cos(pi x) for x in [0,2): exact octant reduction, then libm */
+static void sincospi_02(double x, double* s, double* c) {
+    const double PI = 3.14159265358979323846;
+    double sgn_s = 1.0, sgn_c = 1.0;
+    if (x >= 1.0) { x -= 1.0; sgn_s = -1.0; sgn_c = -1.0; } /* sin(pi(x+1)) = -sin, cos = -cos */
+    if (x > 0.5) { x = 1.0 - x; sgn_c = -sgn_c; }          /* reflect about 1/2             */
+    if (x > 0.25) { /* use co-function for accuracy near pi/2 */
+        const double y = 0.5 - x;
+        *s = sgn_s * cos(PI * y);
+        *c = sgn_c * sin(PI * y);
+    } else {
+        *s = sgn_s * sin(PI * x);
+        *c = sgn_c * cos(PI * x);
+    }
+}
+
+/* standard normal for element (dim, chain) of draw `iter` in `stream`:
+ *   block index blk = ((dim >> 3) << 2) | (dim & 3); dims d and d^4 share a block,
+ *   bit 2 of dim selects the Box-Muller branch (0: cos, 1: sin). */
+static double rng_normal(uint64_t seed, uint32_t stream, uint64_t iter, uint64_t chain, int dim) {
+    uint32_t x[4];
+    rng_block(seed, stream, iter, chain, (uint32_t)(((dim >> 3) << 2) | (dim & 3)), x);
+    const double u1 = (double)(((((uint64_t)x[1] << 32) | x[0]) >> 11) + 1) * 0x1.0p-53; /* (0,1] */
+    const double u2 = u53(x[2], x[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi_02(2.0 * u2, &s, &c);
+    return ((dim >> 2) & 1) ? r * s : r * c;
+}
+
+static double rng_uniform(uint64_t seed, uint64_t iter, uint64_t chain) {
+    uint32_t x[4];
+    rng_block(seed, STREAM_UNIFORM, iter, chain, 0xFFFFFFFFu, x);
+    return u53(x[0], x[1]);
+}
+
+/* out[d*ldn + n] = scale_n * z(d, chain0 + n); scale (N) optional else scalar */
+int oracle_philox_normal(uint64_t seed, int stream, uint64_t iter, uint64_t chain0, int D, int64_t N,
+                         int64_t ldn, double scale_scalar, const double* scale_per_chain,
+                         double* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        const double sc = scale_per_chain ? scale_per_chain[n] : scale_scalar;
+        for (int d = 0; d < D; ++d)
+            out[(size_t)d * ldn + n] = rng_normal(seed, (uint32_t)stream, iter, chain0 + n, d) * sc;
+    }
+    return 0;
+}
+
+int oracle_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, double* out) {
+    for (int64_t n = 0; n < N; ++n) out[n] = rng_uniform(seed, iter, chain0 + n);
+    return 0;
+}
+
+/* getSamples loop (src/HMC.py:150-179) driven by the Philox contract:
+ *   iteration i (global index iter0 + i): p = sqrt(mass*kT) * z, u from STREAM_UNIFORM.
+ *   samples_out / momenta_out: (S, D, N) slabs (momenta_out may be NULL),
+ *   reject_out (S, N) bytes, ratio_out (S, N) optional.  q is the state (in/out).
+ */
+int oracle_hmc_run_philox(const oracle_pot* P, int method, double* q, const double* mass,
+                          int64_t N, int64_t ldn, double h, int L, int S, int compat,
+                          uint64_t seed, uint64_t iter0, uint64_t chain0, double kT,
+                          double* samples_out, double* momenta_out, unsigned char* reject_out,
+                          double* ratio_out) {
+    const int D = P->D;
+    double* p = (double*)malloc(sizeof(double) * (size_t)D * ldn);
+    double* u = (double*)malloc(sizeof(double) * N);
+    double* pstd = (double*)malloc(sizeof(double) * N);
+    for (int64_t n = 0; n < N; ++n) pstd[n] = sqrt((mass ? mass[n] : 1.0) * kT);
+    int rc = 0;
+    for (int i = 0; i < S && rc == 0; ++i) {
+        oracle_philox_normal(seed, STREAM_MOMENTUM, iter0 + i, chain0, D, N, ldn, 1.0, pstd, p);
+        oracle_philox_uniform(seed, iter0 + i, chain0, N, u);
+        rc = oracle_hmc_iter(P, method, q, p, u, mass, N, ldn, h, L, compat,
+                             ratio_out ? ratio_out + (size_t)i * N : NULL,
+                             reject_out ? reject_out + (size_t)i * N : NULL);
+        for (int d = 0; d < D; ++d) {
+            memcpy(samples_out + ((size_t)i * D + d) * N, q + (size_t)d * ldn, sizeof(double) * N);
+            if (momenta_out)
+                memcpy(momenta_out + ((size_t)i * D + d) * N, p + (size_t)d * ldn,
+                       sizeof(double) * N);
+        }
+    }
+    free(p); free(u); free(pstd);
+    return rc;
+}
