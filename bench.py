@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- leapfrog-steps x chains / second of the fused ensemble-HMC hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "C2"; per GPU): d = 128 correlated Gaussian with a
+dense precision matrix (Sigma = A A^T/D + I, A = RandomState(0) normals),
+ensemble = 65 536 chains, fp64, stepSize 0.1, simulTime 1.0 -> L = 10 leapfrog steps.
+A "step" is ONE full HMC iteration over the whole ensemble, exactly the body of the
+reference's getSamples loop (src/HMC.py:154-179): momentum draw (in-kernel Philox),
+L leapfrog steps with L+1 gradient evaluations, both Hamiltonians, Metropolis
+accept/reject, and the store of the position AND momentum sample slabs.  Inputs are
+resident in HBM when the timed region starts.  With N > 1 every rank owns its own 65 536
+chains (weak scaling, C4 = 8 x 65 536); the only collective is the RCCL all-gather of the
+final sample slab AFTER the timed region (reported as allgather_ms).
+
+value = K * L * N_total_chains / t, t = max over ranks of the barrier-bracketed wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+D = 128
+N_PER_GPU = 65536
+STEP = 0.1
+SIMUL = 1.0
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix = fp64 vector peak
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def precision_matrix(d):
+    A = np.random.RandomState(0).standard_normal((d, d))
+    Pm = np.linalg.inv(A @ A.T / d + np.eye(d))
+    return 0.5 * (Pm + Pm.T)
+
+
+def flops_per_step_chain(d, L):
+    # gradient mat-vecs (U reuses them) + update + energies
+    return 2.0 * d * d * (L + 1) / L + 11.0 * d + 8.0 * d / L
+
+
+def bytes_per_step_chain(d, L, w=8):
+    # read q, read/draw p, write q sample, write p sample, u, accept byte; per step
+    return (4.0 * d * w + w + 1) / L
+
+
+def cpu_baseline(Pm, L, seconds_target=15.0):
+    """The oracle (CPU restatement of the reference loop; 'port'), all host threads, on a
+    bounded sample of the same workload: same D, L, potential; fewer chains."""
+    from oracle import oracle as orc
+    pot = orc.pot_gauss_dense(np.zeros(D), Pm)
+    threads = orc.max_threads()
+    n_probe = 64 * threads
+    q = orc.philox_normal(1, orc.STREAM_POSITION, 0, 0, D, n_probe)
+    t0 = time.perf_counter()
+    orc.hmc_run_philox(pot, "Leapfrog", q, None, STEP, L, 1, seed=1, want_momenta=True)
+    t_probe = time.perf_counter() - t0
+    n = int(min(N_PER_GPU, max(n_probe, n_probe * seconds_target / max(t_probe, 1e-3))))
+    n -= n % threads
+    q = orc.philox_normal(1, orc.STREAM_POSITION, 0, 0, D, n)
+    t0 = time.perf_counter()
+    orc.hmc_run_philox(pot, "Leapfrog", q, None, STEP, L, 1, seed=1, want_momenta=True)
+    dt = time.perf_counter() - t0
+    return {"value": n * L / dt, "unit": "leapfrog-steps*chains/s", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle/pbbi_oracle.c hmc_run_philox, 1 HMC iteration, D={D}, "
+                      f"{n} chains, L={L}, OpenMP over chains, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=N_PER_GPU, help="chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE",
+                  file=sys.stderr)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import physicsbasedbayesianinference_amd as P
+    from physicsbasedbayesianinference_amd import _lib
+    from physicsbasedbayesianinference_amd.distributed import gather_samples
+
+    lib = _lib.load()  # raises if the HIP extension is missing: no fallback
+    dev = local_rank
+    N, K, W = args.chains, args.steps, args.warmup
+    L = int(SIMUL / STEP)
+    Pm = precision_matrix(D)
+    pot = P.GaussianDense(None, precision=Pm, const=0.0, device=dev)
+    chain0 = rank * N
+    seed = 42
+    stream = torch.cuda.current_stream().cuda_stream
+
+    q_state = torch.empty((D, N), dtype=torch.float64, device=f"cuda:{dev}")
+    _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, chain0, D, N, N, 1.0, None,
+              _lib.F64, dev, q_state.data_ptr(), stream)
+    S_alloc = max(K, W, 1)
+    samples = torch.empty((S_alloc, D, N), dtype=torch.float64, device=f"cuda:{dev}")
+    momenta = torch.empty((S_alloc, D, N), dtype=torch.float64, device=f"cuda:{dev}")
+    reject = torch.empty((S_alloc, N), dtype=torch.uint8, device=f"cuda:{dev}")
+
+    def run(S, iter0):
+        _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q_state.data_ptr(), None,
+                  samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), None, N, N, STEP, L,
+                  S, _lib.COMPAT_P_FROM_OLDQ, seed, iter0, chain0, 1.0, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if W > 0:
+        run(W, 0)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K, W)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    accept = 1.0 - float(reject[:K].float().mean().item())
+
+    # sample collection: ONE all-gather of the last slab over RCCL/xGMI, outside the timed loop
+    allgather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        full = gather_samples(samples[K - 1:K])
+        torch.cuda.synchronize()
+        allgather_ms = (time.perf_counter() - g0) * 1e3
+        assert full.shape == (1, D, N * world)
+
+    if rank == 0:
+        total_chains = N * world
+        value = K * L * total_chains / t
+        kernel_s = dev_ms * 1e-3 / K  # average launch duration from HIP events on the launch stream
+        flops_launch = flops_per_step_chain(D, L) * L * N
+        bytes_launch = bytes_per_step_chain(D, L) * L * N
+        out = {
+            "metric": "leapfrog-steps*chains/sec (node); d=128 Gaussian, ensemble=65536",
+            "value": value,
+            "unit": "leapfrog-steps*chains/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": t * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: d=128 dense-precision Gaussian, fp64, L=10 leapfrog steps "
+                                   "per HMC iteration, in-kernel Philox momentum + Metropolis",
+                       "chains_per_gpu": N, "total_chains": total_chains, "D": D, "L": L,
+                       "stepSize": STEP, "parallelism": f"ensemble-sharded x{world}",
+                       "accept_rate": accept},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_dense_traj<8, LEAPFROG, full>",
+                "achieved": flops_launch / kernel_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": flops_launch / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launch_ms": kernel_s * 1e3,
+                "hbm_algorithmic_GBs": bytes_launch / kernel_s / 1e9,
+                "hbm_frac_of_8TBs": bytes_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
+            },
+        }
+        if allgather_ms is not None:
+            out["allgather_ms"] = allgather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Pm, L)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

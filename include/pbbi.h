@@ -1,0 +1,191 @@
+/*
+ * pbbi.h -- C ABI of libpbbi.so, the MI355X (gfx950) ensemble-HMC hot path.
+ *
+ * Drop-in boundary.  The reference (Anton-Le/PhysicsBasedBayesianInference) has
+ * no FFI layer: its boundary is the Python class API of src/{ensemble,
+ * integrator,HMC,potential}.py.  Each entry point below replaces the arithmetic
+ * behind one of those methods (cited as file:line relative to the reference
+ * root) and is what a ctypes binding in those files would call -- see
+ * INTEGRATION.md for the stub a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no exceptions cross the ABI.
+ *   - Every function returns an int status (PBBI_OK = 0, negative = error
+ *     class); pbbi_last_error() returns a thread-local message for the last
+ *     failure on the calling thread.
+ *   - State arrays are DEVICE pointers owned by the caller (e.g.
+ *     torch.Tensor.data_ptr()); the library never frees or retains them past
+ *     the call.  Layout: (D, N) "ensemble-major" -- element (d, n) at
+ *     [d*ldn + n], chain index n fastest, ldn >= N.  This is the reference's
+ *     np.zeros((numDimensions, numParticles)) C-order layout
+ *     (src/ensemble.py:40-41).  Element type is the potential handle's dtype.
+ *   - `mass` is a device array of N elements or NULL (= all ones, the
+ *     reference default src/ensemble.py:42; NULL also selects the division-free
+ *     fast path, which is exact for unit mass).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Calls are asynchronous with respect to the host.
+ *   - Potential handles are immutable after creation; the library is
+ *     re-entrant; one handle may be used from several streams.
+ *   - There is NO CPU fallback: every entry point launches HIP kernels on the
+ *     handle's device and fails with PBBI_ERR_HIP if that is impossible.
+ *
+ * RNG contract (device "philox" mode; pbbi_hmc_run, pbbi_philox_*)
+ *   Philox-4x32-10, key = (seed_lo32, seed_hi32),
+ *   counter = (chain_lo32, block, iteration_lo32, stream | chain_hi24 << 8),
+ *   where `chain` is the GLOBAL chain index (chain0 + n), so results do not
+ *   depend on how the ensemble is sharded over GPUs.
+ *   Standard normal of element (dim, chain): block = ((dim>>3)<<2) | (dim&3);
+ *     u1 = (((x1:x0)>>11)+1) * 2^-53 in (0,1],  u2 = ((x3:x2)>>11) * 2^-53,
+ *     r = sqrt(-2 ln u1);  z = r*cospi(2 u2) if bit 2 of dim is 0 else r*sinpi(2 u2).
+ *   Metropolis uniform of a chain: block = 0xFFFFFFFF, stream = PBBI_STREAM_UNIFORM,
+ *     u = ((x1:x0)>>11) * 2^-53 in [0,1).
+ *   The integer part is bit-identical to oracle/pbbi_oracle.c; the
+ *   transcendental part agrees to a few ulp (device libm vs host libm).
+ */
+#ifndef PBBI_H
+#define PBBI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBBI_VERSION 100 /* major*100 + minor */
+
+enum { PBBI_OK = 0, PBBI_ERR_INVALID = -1, PBBI_ERR_UNSUPPORTED = -2, PBBI_ERR_HIP = -3 };
+enum { PBBI_F64 = 0, PBBI_F32 = 1 };
+/* method: the two Integrator subclasses, src/integrator.py:94,126 */
+enum { PBBI_LEAPFROG = 0, PBBI_STORMER_VERLET = 1 };
+/* flags */
+enum {
+    /* reproduce src/HMC.py:176: a rejected chain's stored momentum is its OLD POSITION.
+     * Without the flag the stored momentum of a rejected chain is the drawn momentum. */
+    PBBI_COMPAT_P_FROM_OLDQ = 1
+};
+enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2 };
+
+typedef struct pbbi_potential pbbi_potential; /* opaque */
+
+typedef struct {
+    char name[128];
+    char arch[64];
+    int compute_units;
+    int64_t hbm_bytes;
+    int lds_bytes_per_block;
+    int clock_khz;
+} pbbi_devinfo;
+
+/* ---- library ------------------------------------------------------------- */
+int pbbi_version(void);
+const char* pbbi_last_error(void);
+int pbbi_device_count(int* count_out);
+int pbbi_device_info(int device, pbbi_devinfo* out);
+
+/* ---- potentials ----------------------------------------------------------
+ * "potential" in the reference is any callable q(D,) -> scalar with a gradient
+ * callable (D,) -> (D,) (src/integrator.py:73, src/HMC.py:102).  A GPU kernel
+ * cannot call Python, so the closed forms the reference exercises are handles.
+ * All parameter arrays are HOST pointers (float64), copied at creation.
+ *   harmonic   U = 0.5*dot(k, q**2)                     src/potential.py:18-27
+ *   gauss_diag U = 0.5*dot(prec*(q-mu), q-mu) + cst
+ *   gauss_dense U = 0.5*dot(x, P x) + cst, x = q-mu, grad = P x with P symmetric
+ *              (= -multivariate_normal.logpdf, src/tests/test_HMC.py:49,125).
+ *              `precision` is D x D row-major and MUST be symmetric.
+ *   rosenbrock U = sum_{i<D-1} [b (q_{i+1}-q_i^2)^2 + (a-q_i)^2] / s
+ *              (defined by this build).
+ * mean may be NULL (= 0).
+ */
+int pbbi_potential_create_harmonic(int D, const double* springConsts, int dtype, int device,
+                                   pbbi_potential** out);
+int pbbi_potential_create_gauss_diag(int D, const double* mean, const double* prec, double cst,
+                                     int dtype, int device, pbbi_potential** out);
+int pbbi_potential_create_gauss_dense(int D, const double* mean, const double* precision,
+                                      double cst, int dtype, int device, pbbi_potential** out);
+int pbbi_potential_create_rosenbrock(int D, double a, double b, double s, int dtype, int device,
+                                     pbbi_potential** out);
+int pbbi_potential_destroy(pbbi_potential* pot);
+int pbbi_potential_dim(const pbbi_potential* pot);
+int pbbi_potential_dtype(const pbbi_potential* pot);
+int pbbi_potential_device(const pbbi_potential* pot);
+
+/* potential(q[:, n]) and gradient(q[:, n]) for every chain.
+ * U_out: N elements or NULL; grad_out: (D, N) with stride ldn or NULL.
+ * Replaces the user callables the reference invokes per chain
+ * (src/integrator.py:73, src/HMC.py:102,111,114). */
+int pbbi_potential_eval(const pbbi_potential* pot, const void* q, int64_t N, int64_t ldn,
+                        void* U_out, void* grad_out, void* stream);
+
+/* ---- integrators ---------------------------------------------------------
+ * Leapfrog.integrate() src/integrator.py:95-123 / StormerVerlet.integrate()
+ * src/integrator.py:127-165, over the whole ensemble, in place on q and p.
+ * L = numSteps = int(finalTime/stepSize), computed by the host
+ * (src/integrator.py:51).  v_out: optional (D, N) receiving Integrator.v.
+ */
+int pbbi_integrate(const pbbi_potential* pot, int method, void* q, void* p, const void* mass,
+                   void* v_out, int64_t N, int64_t ldn, double h, int L, void* stream);
+int pbbi_leapfrog(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
+                  int64_t ldn, double h, int L, void* stream);
+int pbbi_stormer_verlet(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
+                        int64_t ldn, double h, int L, void* stream);
+
+/* ---- energies ------------------------------------------------------------
+ * H = 0.5*dot(p,p)/mass + potential(q) per chain          src/HMC.py:100-102
+ * pbbi_energy: H_out (N) and/or weight_out (N) = exp(-H)  (HMC.getWeights :86-104)
+ * pbbi_weights_ratio: exp(oldH - newH)                    (HMC.getWeightsRatio :106-116)
+ */
+int pbbi_energy(const pbbi_potential* pot, const void* q, const void* p, const void* mass,
+                int64_t N, int64_t ldn, void* H_out, void* weight_out, void* stream);
+int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* newP,
+                       const void* oldQ, const void* oldP, const void* mass, int64_t N,
+                       int64_t ldn, void* ratio_out, void* stream);
+
+/* ---- fused HMC iteration -------------------------------------------------
+ * One pass of the body of HMC.getSamples' loop, src/HMC.py:154-179, fused:
+ * integrate -> energies -> ratio -> reject mask -> select -> store.
+ *   q_in  (D,N) chain state;  p_in (D,N) freshly drawn momentum;  u_in (N) uniforms
+ *   q_out (D,N) <- samples_hmc[:,:,i]   (may alias q_in)
+ *   p_out (D,N) <- momentum_hmc[:,:,i]  (may alias p_in; may be NULL)
+ *   ratio_out (N) optional; reject_out (N bytes, 1 = rejected) optional.
+ * Parity mode: the host uploads the NumPy RandomState stream into p_in / u_in.
+ */
+int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                  const void* u_in, const void* mass, void* q_out, void* p_out, void* ratio_out,
+                  uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags,
+                  void* stream);
+
+/* S iterations of the same loop with momentum and uniforms drawn in-kernel
+ * (RNG contract above): iteration i uses draw index iter0+i, chain n uses the
+ * global index chain0+n, p = sqrt(mass*kT) * z  (src/ensemble.py:88-91 with
+ * kT = boltzmannConst*temperature).
+ *   q_state (D,N; stride ldn): in = current positions, out = positions after S iterations
+ *   samples_out (S, D, N) dense slabs <- samples_hmc   (device layout is S-major;
+ *               the reference's (D,N,S) is a permuted view of it)
+ *   momenta_out (S, D, N) or NULL;  reject_out (S, N) bytes or NULL;
+ *   ratio_out (S, N) or NULL.
+ */
+int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
+                 void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
+                 int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
+                 uint64_t iter0, uint64_t chain0, double kT, void* stream);
+
+/* ---- RNG (device Philox stream) -------------------------------------------
+ * out[d*ldn+n] = scale * z(dim d, chain chain0+n); scale_per_chain (N) overrides
+ * scale when non-NULL.  Device-mode counterpart of Ensemble.setPosition /
+ * setMomentum (src/ensemble.py:63-93).  dtype of out/scale_per_chain = `dtype`. */
+int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t chain0, int D,
+                       int64_t N, int64_t ldn, double scale, const void* scale_per_chain,
+                       int dtype, int device, void* out, void* stream);
+int pbbi_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int dtype,
+                        int device, void* out, void* stream);
+
+/* ---- layout helper --------------------------------------------------------
+ * (S, D, N) device slabs -> the reference's (D, N, S) S-fastest array
+ * (src/HMC.py:136-145,178-179).  Both device pointers, same dtype. */
+int pbbi_transpose_sdn_to_dns(const void* src_sdn, void* dst_dns, int S, int D, int64_t N,
+                              int dtype, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBBI_H */

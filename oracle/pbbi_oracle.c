@@ -69,7 +69,8 @@ int oracle_get_max_threads(void) {
  * the reference (tests/golden/gen_golden.py), which in turn stand in for
  *   - harmonicPotentialND                     src/potential.py:18-27
  *   - -multivariate_normal.logpdf(q, mu, cov) src/tests/test_HMC.py:49,125
- *   - Rosenbrock: defined by the build (last row).
+ *   - Rosenbrock: defined by the build (last row); the scale is
+ *     applied as a multiplication by the pre-computed 1/s (no fp64 division per element).
  */
 static double pot_U(const oracle_pot* P, const double* q) {
     const int D = P->D;
@@ -93,8 +94,9 @@ static double pot_U(const oracle_pot* P, const double* q) {
         }
         return 0.5 * acc + P->cst;
     }
-    case POT_ROSENBROCK: { /* (sum b*t^2 + sum (a-q_i)^2) / s, t = q_{i+1}-q_i^2 */
+    case POT_ROSENBROCK: { /* (sum b*t^2 + sum (a-q_i)^2) * (1/s), t = q_{i+1}-q_i^2 */
         double s1 = 0.0, s2 = 0.0;
+        const double inv_s = 1.0 / P->s;
         for (int i = 0; i + 1 < D; ++i) {
             const double t = q[i + 1] - q[i] * q[i];
             s1 += (P->b * t) * t;
@@ -103,7 +105,7 @@ static double pot_U(const oracle_pot* P, const double* q) {
             const double r = P->a - q[i];
             s2 += r * r;
         }
-        return (s1 + s2) / P->s + P->cst;
+        return (s1 + s2) * inv_s + P->cst;
     }
     }
     return NAN;
@@ -126,14 +128,16 @@ static void pot_grad(const oracle_pot* P, const double* q, double* g) {
             g[i] = gi;
         }
         return;
-    case POT_ROSENBROCK:
+    case POT_ROSENBROCK: {
+        const double inv_s = 1.0 / P->s;
         for (int d = 0; d < D; ++d) g[d] = 0.0;
         for (int i = 0; i + 1 < D; ++i) {
             const double t = q[i + 1] - q[i] * q[i];
-            g[i] += (((-4.0 * P->b) * q[i]) * t - 2.0 * (P->a - q[i])) / P->s;
-            g[i + 1] += ((2.0 * P->b) * t) / P->s;
+            g[i] += (((-4.0 * P->b) * q[i]) * t - 2.0 * (P->a - q[i])) * inv_s;
+            g[i + 1] += ((2.0 * P->b) * t) * inv_s;
         }
         return;
+    }
     }
 }
 

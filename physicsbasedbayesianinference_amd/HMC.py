@@ -1,0 +1,215 @@
+"""HMC -- drop-in for the reference's `src/HMC.py` (ensemble Hamiltonian Monte Carlo).
+
+`HMC(ensemble, simulTime, stepSize, density, potential=None, gradient=None,
+method="Leapfrog")` and `getSamples(numSamples, temperature, qStd)` keep the
+reference's signature, return shapes `(D, N, S)` float64 and semantics
+(src/HMC.py:26-71, 123-183).  The body of the reference's sampling loop --
+integrate, energies, ratio, accept/reject, record (src/HMC.py:154-179) -- is ONE
+fused HIP kernel launch per iteration over the whole ensemble.
+
+Two RNG modes:
+  rng="numpy"  (default, reference parity): positions, momenta and uniforms come
+      from NumPy's global legacy RandomState in the reference's order (D*N normals
+      per iteration, then N uniforms; src/ensemble.py:72-74,88-91, src/HMC.py:168)
+      and are uploaded; `np.random.seed(s)` therefore reproduces the reference run.
+  rng="philox" (throughput): everything is drawn inside the kernels from the
+      counter-based stream of include/pbbi.h; the chain state never leaves HBM.
+
+`compat=True` (default) reproduces the reference's quirks:
+rejected chains record their OLD POSITION as momentum (src/HMC.py:176); momenta are
+stored un-negated (:164,:179); a NaN ratio is accepted (:168-173); the accept test
+uses beta = 1 whatever `temperature` is (:115).  `compat=False` only changes the
+first: a rejected chain then records the momentum it drew.
+"""
+import numpy as np
+from scipy.constants import Boltzmann as boltzmannConst
+
+from . import _lib
+from ._device import as_device, empty, stream_ptr, synchronize, to_numpy
+from .integrator import Leapfrog, StormerVerlet, mass_or_none, resolve_potential
+
+__all__ = ["HMC"]
+
+
+class HMC:
+    def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
+                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True):
+        self.ensemble = ensemble
+        self.simulTime = simulTime
+        self.stepSize = stepSize
+        self.density = density
+        self.compat = bool(compat)
+        self.rng = rng
+        self.seed = int(seed)
+        self.verbose = verbose
+
+        # potential: given descriptor, else the descriptor behind `density` (-log density)
+        if potential:
+            self._pot = resolve_potential(potential, "potential")
+            self.potential = potential
+        else:
+            self._pot = resolve_potential(density, "density")
+            self.potential = self.potentialFunc
+        if gradient:
+            if resolve_potential(gradient, "gradient") is not self._pot:
+                raise ValueError("gradient= must belong to the same descriptor as potential=")
+            self.gradient = gradient
+        else:
+            self.gradient = self._pot.gradient  # stands in for jax.grad(self.potential) (:60)
+
+        if method == "Leapfrog":
+            self.integrator = Leapfrog(ensemble, stepSize, simulTime, self.gradient)
+        elif method == "Stormer-Verlet":
+            self.integrator = StormerVerlet(ensemble, stepSize, simulTime, self.gradient)
+        else:
+            raise ValueError("Invalid integration method selected.")
+        self.method = method
+        # diagnostics of the last getSamples call
+        self.reject_masks = None   # (S, N) bool
+        self.ratios = None         # (S, N) exp(oldH - newH)
+        self.acceptRate = None
+
+    # ------------------------------------------------------------------ helpers
+    def potentialFunc(self, q):
+        """U(q) = -log(density(q))  (src/HMC.py:75-84)."""
+        return -np.log(self.density(q))
+
+    def _upload_state(self, *arrays):
+        pot = self._pot
+        D, N = self.ensemble.numDimensions, self.ensemble.numParticles
+        out = []
+        for a in arrays:
+            a = np.asarray(a)
+            if a.shape != (D, N):
+                raise ValueError(f"expected a ({D}, {N}) array, got {a.shape}")
+            out.append(as_device(a, pot.device, pot.dtype))
+        return out
+
+    def _mass(self):
+        pot = self._pot
+        return mass_or_none(self.ensemble.mass, self.ensemble.numParticles, pot.dtype, pot.device)
+
+    def getWeights(self, q, p):
+        """exp(-H) per chain, H = 0.5*dot(p,p)/mass + potential(q)   (src/HMC.py:86-104)."""
+        pot = self._pot
+        N = self.ensemble.numParticles
+        qd, pd = self._upload_state(q, p)
+        md = self._mass()
+        w = empty((N,), pot.dtype, pot.device)
+        _lib.call("pbbi_energy", pot.handle, qd.data_ptr(), pd.data_ptr(),
+                  md.data_ptr() if md is not None else None, N, N, None, w.data_ptr(),
+                  stream_ptr(pot.device))
+        return to_numpy(w)
+
+    def getWeightsRatio(self, newQ, newP, oldQ, oldP):
+        """exp(oldH - newH) per chain   (src/HMC.py:106-116)."""
+        pot = self._pot
+        N = self.ensemble.numParticles
+        nq, np_, oq, op = self._upload_state(newQ, newP, oldQ, oldP)
+        md = self._mass()
+        r = empty((N,), pot.dtype, pot.device)
+        _lib.call("pbbi_weights_ratio", pot.handle, nq.data_ptr(), np_.data_ptr(), oq.data_ptr(),
+                  op.data_ptr(), md.data_ptr() if md is not None else None, N, N, r.data_ptr(),
+                  stream_ptr(pot.device))
+        return to_numpy(r)
+
+    def print_information(self):
+        print("integrator: ", self.integrator)
+        print("final integration time: ", self.simulTime)
+        print("time step: ", self.stepSize)
+
+    # ------------------------------------------------------------------ sampling
+    def getSamples(self, numSamples, temperature, qStd, rng=None, seed=None, device_output=False,
+                   chain0=0, iter0=0, host_stream=None):
+        """HMC.getSamples (src/HMC.py:123-183): returns (samples_hmc, momentum_hmc), each
+        (D, N, numSamples) with the sample index fastest.
+
+        Extra keyword-only behaviour (not in the reference): rng / seed override the
+        constructor's; device_output=True returns torch tensors that are (D, N, S)
+        *views* of the (S, D, N) device slabs (no transpose pass, no D2H copy).
+        chain0 / iter0 offset the Philox counters (ensemble sharding / resuming);
+        host_stream (distributed.HostStream) makes rng="numpy" keep only this shard's
+        columns of the global NumPy stream.
+        """
+        pot = self._pot
+        ens = self.ensemble
+        D, N, S = ens.numDimensions, ens.numParticles, int(numSamples)
+        if D != pot.numDimensions:
+            raise ValueError(f"potential has D={pot.numDimensions}, ensemble has D={D}")
+        rng = self.rng if rng is None else rng
+        seed = self.seed if seed is None else int(seed)
+        L = self.integrator.numSteps
+        h = float(self.stepSize)
+        flags = _lib.COMPAT_P_FROM_OLDQ if self.compat else 0
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+
+        samples = empty((S, D, N), dt, dev)
+        momenta = empty((S, D, N), dt, dev)
+        reject = empty((S, N), np.uint8, dev)
+        ratio = empty((S, N), dt, dev)
+        md = self._mass()
+        mptr = md.data_ptr() if md is not None else None
+
+        if self.verbose:
+            self.print_information()
+        if rng == "numpy":
+            # identical RNG consumption to the reference: q0, then per iteration p then u
+            if host_stream is None:
+                self.integrator.q = ens.setPosition(qStd)                   # :148
+            else:
+                self.integrator.q = ens.q = host_stream.positions(qStd)
+            q_prev = as_device(self.integrator.q, dev, dt)
+            for i in range(S):
+                if self.verbose and i % 100 == 0:
+                    print("HMC iteration ", i + 1)                           # :151-152
+                if host_stream is None:
+                    self.integrator.p = ens.setMomentum(temperature)        # :154
+                    u = np.random.uniform(size=N)                            # :168
+                else:
+                    self.integrator.p = ens.p = host_stream.momenta(ens.mass, temperature)
+                    u = host_stream.uniforms()
+                pd = as_device(self.integrator.p, dev, dt)
+                ud = as_device(u, dev, dt)
+                _lib.call("pbbi_hmc_iter", pot.handle, self.integrator.method_id,
+                          q_prev.data_ptr(), pd.data_ptr(), ud.data_ptr(), mptr,
+                          samples[i].data_ptr(), momenta[i].data_ptr(), ratio[i].data_ptr(),
+                          reject[i].data_ptr(), N, N, h, L, flags, stream)
+                q_prev = samples[i]
+        elif rng == "philox":
+            kT = float(boltzmannConst * temperature)                         # src/ensemble.py:88
+            q_state = empty((D, N), dt, dev)
+            _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D,
+                      N, N, float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
+            _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                      mptr, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
+                      ratio.data_ptr(), N, N, h, L, S, flags, seed, int(iter0), int(chain0), kT,
+                      stream)
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+
+        synchronize(dev)
+        self.reject_masks = to_numpy(reject).astype(bool)
+        self.ratios = to_numpy(ratio)
+        self.acceptRate = 1.0 - float(self.reject_masks.mean()) if S > 0 else None
+        if S > 0:
+            # leave the ensemble where the reference leaves it: q, p alias the final state
+            if rng != "numpy":
+                self.integrator.q = ens.q = np.empty((D, N))
+                self.integrator.p = ens.p = np.empty((D, N))
+            self.integrator.q[...] = to_numpy(samples[S - 1])
+            self.integrator.p[...] = to_numpy(momenta[S - 1])
+        if device_output:
+            return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
+        return self._to_dns(samples), self._to_dns(momenta)
+
+    def _to_dns(self, sdn):
+        """(S, D, N) device slabs -> host (D, N, S) array via the LDS-tiled transpose kernel."""
+        pot = self._pot
+        S, D, N = sdn.shape
+        if S == 0:
+            return np.zeros((D, N, 0))
+        out = empty((D, N, S), pot.dtype, pot.device)
+        _lib.call("pbbi_transpose_sdn_to_dns", sdn.data_ptr(), out.data_ptr(), S, D, N, pot._dt,
+                  pot.device, stream_ptr(pot.device))
+        return to_numpy(out).astype(np.float64, copy=False)

@@ -1,0 +1,605 @@
+// kernels_dense.hip -- dense-precision Gaussian potential, D <= 128, fp64, gfx950.
+//
+// The gradient of U = 0.5 x^T P x is the batched mat-vec G = P X over the ensemble
+// (x = q - mu): a (DP x DP)·(DP x 16) product per 16-chain tile, done on the matrix cores
+// with v_mfma_f64_16x16x4_f64.  Design (MI355X-first, not a translation of anything):
+//
+//   * One wave owns a tile of 16 chains for the WHOLE trajectory.  Its q, v, a and the
+//     mat-vec accumulator live in VGPR/AGPRs: lane (g = lane>>4, c = lane&15) holds, for
+//     chain c, the dims {4s+g : s = 0..DP/4-1}.  That is simultaneously
+//        - the B-operand layout of K-step s      (B[k = lane>>4][n = lane&15]), and
+//        - the C/D layout of row tile t, reg r   (row = (lane>>4) + 4r -> dim 16t+4r+g, s = 4t+r),
+//     so the MFMA output lands exactly where the next step's operand lives: the
+//     leapfrog update is lane-local, no shuffles, no LDS round trip for state.
+//   * P (128 KiB at D=128) is staged ONCE per workgroup into LDS, pre-swizzled on the host
+//     into A-fragment order [s][t/2][lane][2] so that each ds_read_b128 is lane-linear
+//     (conflict-free) and feeds two MFMAs.  mu sits next to it (1 KiB).
+//   * Workgroups are persistent: grid = min(#tiles, #CUs), grid-stride over 64-chain
+//     tiles; 129 KiB of LDS pins one workgroup (4 waves, one per SIMD) per CU, and a
+//     wave may use the full 512-register budget.
+//   * U(q) = 0.5 x.(P x) reuses the gradient mat-vec (first and last evaluation of the
+//     trajectory), so an HMC iteration costs exactly L+1 mat-vecs.
+//   * Kinetic/potential sums: 32 lane-local terms, then a 2-step xor butterfly over the
+//     4 lanes that share a chain (every lane ends with identical bits -> uniform decision).
+//
+// Arithmetic per element follows the reference's operation order (src/integrator.py:105-120,
+// :142-163; src/HMC.py:100-102,115,164-179); only the summation ORDER inside dot products
+// differs from the oracle (MFMA k-ordered fma chain, lane-group butterfly), so parity with
+// the oracle is to fp64 tolerance with equal reject masks, not bitwise.
+#include <vector>
+
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+constexpr int BLOCK = 256;          // 4 waves, one per SIMD
+constexpr int CHAINS_PER_WAVE = 16;
+constexpr int CHAINS_PER_WG = 64;
+
+struct DensePrm {
+    const double* frag;   // DP*DP, A-fragment order
+    const double* mu;     // DP, zero padded
+    const double* q_in;
+    const double* p_in;
+    const double* u_in;
+    const double* mass;
+    double* q_out;
+    double* p_out;
+    double* v_out;
+    double* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    double h, cst, kT;
+    int L, D, flags, rng, mode;  // mode 0: HMC iteration, 1: integrate only (in place)
+    uint64_t seed, iter, chain0;
+};
+
+template <int NT>
+__device__ __forceinline__ void stage_lds(const double* __restrict__ gfrag,
+                                          const double* __restrict__ gmu, v2f64* frag2,
+                                          double* mu) {
+    constexpr int DP = 16 * NT;
+    const v2f64* src = reinterpret_cast<const v2f64*>(gfrag);
+    for (int i = threadIdx.x; i < DP * DP / 2; i += BLOCK) frag2[i] = src[i];
+    for (int i = threadIdx.x; i < DP; i += BLOCK) mu[i] = gmu[i];
+    __syncthreads();
+}
+
+// acc[t][r] (dim 16t+4r+g) = sum_j P[dim][j] * (q_j - mu_j) for the wave's 16 chains.
+// fragL = frag2 + lane, muG = mu + g.  Software-pipelined by hand: the A fragments and mu of
+// K-step s+1 are fetched from LDS before the NT MFMAs of K-step s issue; the sched_barrier
+// pins that shape (left alone, the scheduler hoists every ds_read of the unrolled loop to
+// the top and spills hundreds of VGPRs).
+template <int NT>
+__device__ __forceinline__ void matvec(const v2f64* __restrict__ fragL,
+                                       const double* __restrict__ muG,
+                                       const double (&q)[4 * NT], v4f64 (&acc)[NT]) {
+    constexpr int KS = 4 * NT;
+    constexpr int H = NT / 2;
+    v2f64 A[H], An[H];
+    double m0 = muG[0], mn = 0.0;
+#pragma unroll
+    for (int t2 = 0; t2 < H; ++t2) A[t2] = fragL[t2 * 64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int t2 = 0; t2 < H; ++t2) An[t2] = fragL[((s + 1) * H + t2) * 64];
+            mn = muG[4 * (s + 1)];
+        }
+        const double x = q[s] - m0;
+#pragma unroll
+        for (int t2 = 0; t2 < H; ++t2) {
+            acc[2 * t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].x, x, acc[2 * t2], 0, 0, 0);
+            acc[2 * t2 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].y, x, acc[2 * t2 + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 0; t2 < H; ++t2) A[t2] = An[t2];
+        m0 = mn;
+    }
+}
+
+// sum over the 4 lanes (g = 0..3) that hold one chain; identical bits in all four.
+__device__ __forceinline__ double chain_sum(double x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+template <int NT>
+__device__ __forceinline__ double dot_x_acc(const double* __restrict__ muG,
+                                             const double (&q)[4 * NT], const v4f64 (&acc)[NT]) {
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * t + r;
+            sum += (q[s] - muG[4 * s]) * acc[t][r];
+        }
+    return sum;
+}
+
+// State element s of this lane lives at row 4s+g, column (tile base + cc):
+//   address = tile base [uniform, one SGPR pair per array] + 8 * (voff + s*stride4)
+// with voff = g*ld + cc and stride4 = 4*ld as 32-bit lane offsets (host checks DP*ld < 2^29).
+// All validity branches are on kernel arguments only (uniform, scalar branches): rows
+// 4s..4s+3 are all inside D, partly inside (only when D % 4 != 0) or all padding.
+// FULL (D == DP, no padded rows) compiles every branch away.
+template <bool FULL>
+__device__ __forceinline__ double load_elem(const double* __restrict__ base, uint32_t voff,
+                                            uint32_t stride4, uint32_t ld, int s, int g, int D) {
+    if constexpr (FULL) return base[voff + (uint32_t)s * stride4];
+    double val = 0.0;
+    if (4 * s + 3 < D) {
+        val = base[voff + (uint32_t)s * stride4];
+    } else if (4 * s < D) {  // partial row group: out-of-range lanes read row 4s and discard
+        const bool ok = 4 * s + g < D;
+        const double t = base[voff + (uint32_t)s * stride4 - (ok ? 0u : (uint32_t)g * ld)];
+        val = ok ? t : 0.0;
+    }
+    return val;
+}
+
+template <bool FULL>
+__device__ __forceinline__ void store_elem(double* __restrict__ base, uint32_t voff,
+                                           uint32_t stride4, int s, int g, int D, double val) {
+    if constexpr (FULL) {
+        base[voff + (uint32_t)s * stride4] = val;
+        return;
+    }
+    if (4 * s + 3 < D) {
+        base[voff + (uint32_t)s * stride4] = val;
+    } else if (4 * s < D) {
+        if (4 * s + g < D) base[voff + (uint32_t)s * stride4] = val;
+    }
+}
+
+template <int NT, int METHOD, bool FULL>
+__global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
+    constexpr int DP = 16 * NT;
+    constexpr int KS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f64* frag2 = reinterpret_cast<v2f64*>(smem);
+    double* mu = reinterpret_cast<double*>(smem + (size_t)DP * DP * sizeof(double));
+    stage_lds<NT>(prm.frag, prm.mu, frag2, mu);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int c = lane & 15;
+    const v2f64* fragL = frag2 + lane;
+    const double* muG = mu + g;
+    const int D = prm.D;
+    const bool unit = (prm.mass == nullptr);
+    const double h = prm.h, h2 = prm.h * prm.h;
+    const int64_t n_wg_tiles = (prm.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG;
+
+    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
+        const int64_t n0 = (wt * 4 + wave) * CHAINS_PER_WAVE;  // wave-uniform
+        if (n0 >= prm.N) continue;
+        const int64_t left = prm.N - n0;
+        const bool valid = c < left;
+        const int cc = valid ? c : (int)left - 1;  // ragged tail: compute on a clamped chain
+        const uint32_t ld_in = (uint32_t)prm.ldn_in, ld_out = (uint32_t)prm.ldn_out;
+        const uint32_t vin = (uint32_t)g * ld_in + (uint32_t)cc, s4in = 4u * ld_in;
+        const uint32_t vout = (uint32_t)g * ld_out + (uint32_t)cc, s4out = 4u * ld_out;
+        const double* qin = prm.q_in + n0;
+        const double* pin = prm.p_in + n0;
+        double* qout = prm.q_out + n0;
+        double* pout = prm.p_out ? prm.p_out + n0 : nullptr;
+        const double m = unit ? 1.0 : prm.mass[n0 + cc];
+        const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+
+        double q[KS], v[KS], a[KS];
+        v4f64 acc[NT];
+        // ---- momentum first (v holds p until the division by mass below); q is fetched
+        //      afterwards so that it is not live across the register-hungry RNG code.
+        double u = 0.0;
+        if (prm.rng) {
+            const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {
+                double zc, zs;
+                rng_normal_pair(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain,
+                                (uint32_t)(((s >> 1) << 2) | g), zc, zs);
+                v[s] = (FULL || 4 * s + g < D) ? zc * pstd : 0.0;
+                v[s + 1] = (FULL || 4 * (s + 1) + g < D) ? zs * pstd : 0.0;
+                __builtin_amdgcn_sched_barrier(0);  // one Philox/Box-Muller body at a time
+            }
+            u = rng_uniform(prm.seed, prm.iter, chain);
+            if (pout && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid) {
+                // non-compat: a rejected chain reports its drawn momentum; park the draw now
+                // (accepted chains overwrite it below) rather than regenerate it later.
+#pragma unroll
+                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, v[s]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
+            if (prm.mode == 0) u = prm.u_in[n0 + cc];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+        double pp_old = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pp_old += v[s] * v[s];
+        if (!unit) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v[s] = v[s] / m;  // v = p/m  (:106,:143)
+        }
+
+        // ---- first gradient evaluation; doubles as U(q_old)
+        matvec<NT>(fragL, muG, q, acc);
+        double xg_old = dot_x_acc<NT>(muG, q, acc);
+        double xg_new = xg_old;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[4 * t + r] = unit ? -acc[t][r] : -acc[t][r] / m;
+
+        if constexpr (METHOD == PBBI_LEAPFROG) {
+            for (int j = 0; j < prm.L; ++j) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) q[s] += (v[s] * h + (0.5 * a[s]) * h2);  // :112-115
+                matvec<NT>(fragL, muG, q, acc);                                       // :116
+                if (j == prm.L - 1) xg_new = dot_x_acc<NT>(muG, q, acc);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = 4 * t + r;
+                        const double an = unit ? -acc[t][r] : -acc[t][r] / m;
+                        v[s] += (0.5 * (a[s] + an)) * h;  // :117
+                        a[s] = an;
+                    }
+            }
+        } else {  // Stormer-Verlet, src/integrator.py:142-163 (a[] becomes qPast)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double q0 = q[s];
+                q[s] = (q0 + v[s] * h) + (0.5 * a[s]) * h2;  // :145-150
+                a[s] = q0;                                   // qPast
+            }
+            for (int j = 0; j < prm.L; ++j) {
+                matvec<NT>(fragL, muG, q, acc);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = 4 * t + r;
+                        const double an = unit ? -acc[t][r] : -acc[t][r] / m;
+                        const double cur = q[s];
+                        q[s] = (2 * cur - a[s]) + an * h2;  // :155-159
+                        a[s] = cur;
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v[s] = (q[s] - a[s]) / h;  // :162
+            if (prm.mode == 0) {  // U(q_new) needs its own mat-vec here
+                matvec<NT>(fragL, muG, q, acc);
+                xg_new = dot_x_acc<NT>(muG, q, acc);
+            }
+        }
+
+        if (prm.mode == 1) {  // integrate(): in place q, p; optional Integrator.v
+            double* vout_p = prm.v_out ? prm.v_out + n0 : nullptr;
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);
+                    store_elem<FULL>(pout, vout, s4out, s, g, D, unit ? v[s] : v[s] * m);
+                }
+                if (vout_p) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) store_elem<FULL>(vout_p, vout, s4out, s, g, D, v[s]);
+                }
+            }
+            continue;
+        }
+
+        // ---- energies, ratio, decision (src/HMC.py:109-115,166-173)
+        double pp_new = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            v[s] = unit ? v[s] : v[s] * m;  // p = v*m  (:119); v now holds p
+            pp_new += v[s] * v[s];
+        }
+        pp_old = chain_sum(pp_old);
+        pp_new = chain_sum(pp_new);
+        xg_old = chain_sum(xg_old);
+        xg_new = chain_sum(xg_new);
+        const double oldH = 0.5 * pp_old / m + (0.5 * xg_old + prm.cst);
+        const double newH = 0.5 * pp_new / m + (0.5 * xg_new + prm.cst);
+        const double ratio = exp(oldH - newH);
+        const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+        const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
+        bool store_p = (pout != nullptr);
+        if (reject) {  // rare: fetch the old point again instead of keeping 64 more VGPRs live
+#pragma unroll
+            for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);  // :175
+            if (compat) {  // :176  p <- oldQ
+#pragma unroll
+                for (int s = 0; s < KS; ++s) v[s] = q[s];
+            } else if (prm.rng) {
+                store_p = false;  // the parked draw stays
+            } else if (pout) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) v[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);  // :178
+            if (store_p) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, v[s]);  // :179
+            }
+        }
+        if (valid && g == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+        }
+    }
+}
+
+struct DenseEvalPrm {
+    const double* frag;
+    const double* mu;
+    const double* q;
+    const double* p;
+    const double* mass;
+    double* U_out;
+    double* grad_out;
+    double* w_out;
+    int64_t N, ldn;
+    double cst;
+    int D, mode;  // 0: U / grad; 1: H / exp(-H); 2: U_out = exp(U_out - H)
+};
+
+template <int NT, bool FULL>
+__global__ void __launch_bounds__(BLOCK, 1) k_dense_eval(DenseEvalPrm prm) {
+    constexpr int DP = 16 * NT;
+    constexpr int KS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f64* frag2 = reinterpret_cast<v2f64*>(smem);
+    double* mu = reinterpret_cast<double*>(smem + (size_t)DP * DP * sizeof(double));
+    stage_lds<NT>(prm.frag, prm.mu, frag2, mu);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const v2f64* fragL = frag2 + lane;
+    const double* muG = mu + g;
+    const int D = prm.D;
+    const int64_t n_wg_tiles = (prm.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG;
+    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
+        const int64_t n0 = (wt * 4 + wave) * CHAINS_PER_WAVE;
+        if (n0 >= prm.N) continue;
+        const int64_t left = prm.N - n0;
+        const bool valid = c < left;
+        const int cc = valid ? c : (int)left - 1;
+        const uint32_t ld = (uint32_t)prm.ldn;
+        const uint32_t voff = (uint32_t)g * ld + (uint32_t)cc, s4 = 4u * ld;
+        const double* qin = prm.q + n0;
+        double q[KS];
+        v4f64 acc[NT];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, voff, s4, ld, s, g, D);
+        matvec<NT>(fragL, muG, q, acc);
+        const double xg = chain_sum(dot_x_acc<NT>(muG, q, acc));
+        const double U = 0.5 * xg + prm.cst;
+        if (prm.mode == 0) {
+            if (prm.grad_out) {
+                double* gout = prm.grad_out + n0;
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            store_elem<FULL>(gout, voff, s4, 4 * t + r, g, D, acc[t][r]);
+                }
+            }
+            if (prm.U_out && valid && g == 0) prm.U_out[n0 + c] = U;
+            continue;
+        }
+        const double* pin = prm.p + n0;
+        double pp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double pv = load_elem<FULL>(pin, voff, s4, ld, s, g, D);
+            pp += pv * pv;
+        }
+        pp = chain_sum(pp);
+        const double m = prm.mass ? prm.mass[n0 + cc] : 1.0;
+        const double H = 0.5 * pp / m + U;
+        if (valid && g == 0) {
+            if (prm.mode == 1) {
+                if (prm.U_out) prm.U_out[n0 + c] = H;
+                if (prm.w_out) prm.w_out[n0 + c] = exp(-H);
+            } else {
+                prm.U_out[n0 + c] = exp(prm.U_out[n0 + c] - H);
+            }
+        }
+    }
+}
+
+int num_cus(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+        cus <= 0)
+        cus = 256;
+    if (device >= 0 && device < 64) cached[device] = cus;
+    return cus;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PBBI_OK;
+}
+
+inline size_t lds_bytes(int DP) { return (size_t)DP * DP * 8 + (size_t)DP * 8; }
+
+inline unsigned grid_size(const pbbi_potential* pot, int64_t N) {
+    const int64_t tiles = (N + CHAINS_PER_WG - 1) / CHAINS_PER_WG;
+    const int64_t cus = num_cus(pot->device);
+    return (unsigned)(tiles < cus ? tiles : cus);
+}
+
+int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int64_t N,
+                hipStream_t stream) {
+    const size_t lds = lds_bytes(pot->DP);
+    const dim3 grid(grid_size(pot, N)), block(BLOCK);
+    const bool full = (pot->D == pot->DP);
+#define LAUNCH(NT_, M_, F_)                                                          \
+    {                                                                                \
+        if (int rc = set_lds(k_dense_traj<NT_, M_, F_>, lds)) return rc;             \
+        hipLaunchKernelGGL((k_dense_traj<NT_, M_, F_>), grid, block, lds, stream, prm); \
+    }
+#define CASE(NT_)                                                 \
+    if (pot->DP == 16 * NT_) {                                    \
+        if (method == PBBI_LEAPFROG) {                            \
+            if (full) LAUNCH(NT_, PBBI_LEAPFROG, true)            \
+            else LAUNCH(NT_, PBBI_LEAPFROG, false)                \
+        } else {                                                  \
+            if (full) LAUNCH(NT_, PBBI_STORMER_VERLET, true)      \
+            else LAUNCH(NT_, PBBI_STORMER_VERLET, false)          \
+        }                                                         \
+    }
+    CASE(2) CASE(4) CASE(8)
+#undef CASE
+#undef LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int check_ld(const pbbi_potential* pot, int64_t ld) {
+    if ((int64_t)pot->DP * ld >= ((int64_t)1 << 29))
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
+                         "dense kernels address a lane's rows with 32-bit offsets: padded D * "
+                         "leading stride must be < 2^29 elements; shard the ensemble");
+    return PBBI_OK;
+}
+
+int check(const pbbi_potential* pot) {
+    if (pot->dtype != PBBI_F64)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian kernels are fp64 only in this build");
+    if (pot->DP == 0 || pot->d_frag == nullptr)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
+                         "dense Gaussian: register-resident MFMA path needs D <= 128 (D = " +
+                             std::to_string(pot->D) + ")");
+    return PBBI_OK;
+}
+
+}  // namespace
+
+// P (row-major, D x D) -> A-fragment order [s][t/2][lane][t&1], zero padded to DP.
+// Lane l of fragment (s, t) supplies A[i = l&15][k = l>>4] = P[16t + (l&15)][4s + (l>>4)].
+int dense_build_fragments(pbbi_potential* pot, const double* P, const double* mean) {
+    const int D = pot->D;
+    pot->DP = 0;
+    pot->d_frag = nullptr;
+    pot->d_mean_pad = nullptr;
+    if (D > 128 || pot->dtype != PBBI_F64) return PBBI_OK;  // path unavailable; callers check
+    const int DP = D <= 32 ? 32 : (D <= 64 ? 64 : 128);
+    const int NT = DP / 16, KS = DP / 4;
+    std::vector<double> frag((size_t)DP * DP, 0.0), mu((size_t)DP, 0.0);
+    for (int s = 0; s < KS; ++s)
+        for (int t = 0; t < NT; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int i = 16 * t + (l & 15), k = 4 * s + (l >> 4);
+                const double val = (i < D && k < D) ? P[(size_t)i * D + k] : 0.0;
+                frag[(((size_t)s * (NT / 2) + t / 2) * 64 + l) * 2 + (t & 1)] = val;
+            }
+    for (int d = 0; d < D; ++d) mu[d] = mean ? mean[d] : 0.0;
+    PBBI_HIP(hipMalloc(&pot->d_frag, frag.size() * sizeof(double)));
+    PBBI_HIP(hipMalloc(&pot->d_mean_pad, mu.size() * sizeof(double)));
+    PBBI_HIP(hipMemcpy(pot->d_frag, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice));
+    PBBI_HIP(hipMemcpy(pot->d_mean_pad, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
+    pot->DP = DP;
+    return PBBI_OK;
+}
+
+int dense_hmc_iter(const IterArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    DensePrm prm{};
+    prm.frag = (const double*)a.pot->d_frag;
+    prm.mu = (const double*)a.pot->d_mean_pad;
+    prm.q_in = (const double*)a.q_in;
+    prm.p_in = (const double*)a.p_in;
+    prm.u_in = (const double*)a.u_in;
+    prm.mass = (const double*)a.mass;
+    prm.q_out = (double*)a.q_out;
+    prm.p_out = (double*)a.p_out;
+    prm.v_out = nullptr;
+    prm.ratio_out = (double*)a.ratio_out;
+    prm.reject_out = a.reject_out;
+    prm.N = a.N; prm.ldn_in = a.ldn_in; prm.ldn_out = a.ldn_out;
+    prm.h = a.h; prm.cst = a.pot->cst; prm.kT = a.kT;
+    prm.L = a.L; prm.D = a.pot->D; prm.flags = a.flags; prm.rng = a.rng; prm.mode = 0;
+    prm.seed = a.seed; prm.iter = a.iter; prm.chain0 = a.chain0;
+    return launch_traj(a.pot, a.method, prm, a.N, a.stream);
+}
+
+int dense_integrate(const IntegrateArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    DensePrm prm{};
+    prm.frag = (const double*)a.pot->d_frag;
+    prm.mu = (const double*)a.pot->d_mean_pad;
+    prm.q_in = (const double*)a.q;
+    prm.p_in = (const double*)a.p;
+    prm.mass = (const double*)a.mass;
+    prm.q_out = (double*)a.q;
+    prm.p_out = (double*)a.p;
+    prm.v_out = (double*)a.v_out;
+    prm.N = a.N; prm.ldn_in = a.ldn; prm.ldn_out = a.ldn;
+    prm.h = a.h; prm.cst = a.pot->cst; prm.kT = 1.0;
+    prm.L = a.L; prm.D = a.pot->D; prm.mode = 1;
+    return launch_traj(a.pot, a.method, prm, a.N, a.stream);
+}
+
+static int dense_eval_launch(const EvalArgs& a, int mode) {
+    if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    const pbbi_potential* pot = a.pot;
+    DenseEvalPrm prm{(const double*)pot->d_frag, (const double*)pot->d_mean_pad,
+                     (const double*)a.q, (const double*)a.p, (const double*)a.mass,
+                     (double*)a.U_out, (double*)a.grad_out, (double*)a.w_out,
+                     a.N, a.ldn, pot->cst, pot->D, mode};
+    const size_t lds = lds_bytes(pot->DP);
+    const dim3 grid(grid_size(pot, a.N)), block(BLOCK);
+    const bool full = (pot->D == pot->DP);
+#define LAUNCH(NT_, F_)                                                               \
+    {                                                                                 \
+        if (int rc = set_lds(k_dense_eval<NT_, F_>, lds)) return rc;                  \
+        hipLaunchKernelGGL((k_dense_eval<NT_, F_>), grid, block, lds, a.stream, prm); \
+    }
+#define CASE(NT_)                          \
+    if (pot->DP == 16 * NT_) {             \
+        if (full) LAUNCH(NT_, true)        \
+        else LAUNCH(NT_, false)            \
+    }
+    CASE(2) CASE(4) CASE(8)
+#undef CASE
+#undef LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int dense_eval(const EvalArgs& a) { return dense_eval_launch(a, 0); }
+int dense_energy(const EvalArgs& a) { return dense_eval_launch(a, a.ratio_finish ? 2 : 1); }

@@ -1,0 +1,471 @@
+// kernels_lane.hip -- chain-per-lane kernels for potentials whose gradient is elementwise
+// or nearest-neighbour (harmonic, diagonal Gaussian, Rosenbrock), gfx950.
+//
+// One ensemble member ("chain") per lane; its q, v, a live in VGPRs for all L steps, so an
+// HMC iteration touches HBM once on the way in and once on the way out.  The (D, N)
+// chain-fastest layout makes every load/store a 512-byte contiguous segment per wave.
+// Operation order follows the reference exactly (no FMA contraction: built with
+// -ffp-contract=off), so in parity mode these kernels are bit-identical to the oracle
+// for q and p (only exp() of the ratio may differ in the last ulp):
+//   Leapfrog.integrate        src/integrator.py:105-120
+//   StormerVerlet.integrate   src/integrator.py:142-163
+//   H = 0.5*dot(p,p)/m + U    src/HMC.py:100-102,109-115
+//   accept/reject + stores    src/HMC.py:164-179
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------ potentials
+template <typename T, int DMAX>
+struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
+    const T* __restrict__ mean;
+    const T* __restrict__ prec;
+    T cst;
+    int D;
+    int harmonic;
+    __device__ __forceinline__ T U(const T (&q)[DMAX]) const {
+        T acc = T(0);
+        if (harmonic) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                if (d < D) acc += prec[d] * (q[d] * q[d]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                if (d < D) {
+                    const T x = q[d] - mean[d];
+                    acc += (prec[d] * x) * x;
+                }
+        }
+        return T(0.5) * acc + cst;
+    }
+    __device__ __forceinline__ void grad(const T (&q)[DMAX], T (&g)[DMAX]) const {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) g[d] = (d < D) ? prec[d] * (q[d] - mean[d]) : T(0);
+    }
+};
+
+template <typename T, int DMAX>
+struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t = q_{i+1} - q_i^2
+    T a, b, inv_s, cst;
+    int D;
+    __device__ __forceinline__ T U(const T (&q)[DMAX]) const {
+        T s1 = T(0), s2 = T(0);
+#pragma unroll
+        for (int i = 0; i + 1 < DMAX; ++i)
+            if (i + 1 < D) {
+                const T t = q[i + 1] - q[i] * q[i];
+                s1 += (b * t) * t;
+            }
+#pragma unroll
+        for (int i = 0; i + 1 < DMAX; ++i)
+            if (i + 1 < D) {
+                const T r = a - q[i];
+                s2 += r * r;
+            }
+        return (s1 + s2) * inv_s + cst;
+    }
+    __device__ __forceinline__ void grad(const T (&q)[DMAX], T (&g)[DMAX]) const {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) g[d] = T(0);
+#pragma unroll
+        for (int i = 0; i + 1 < DMAX; ++i)
+            if (i + 1 < D) {
+                const T t = q[i + 1] - q[i] * q[i];
+                g[i] += (((T(-4) * b) * q[i]) * t - T(2) * (a - q[i])) * inv_s;
+                g[i + 1] += ((T(2) * b) * t) * inv_s;
+            }
+    }
+};
+
+// ---------------------------------------------------------------- integrators
+template <typename T, typename Pot, int DMAX>
+__device__ __forceinline__ void accel(const Pot& pot, const T (&q)[DMAX], T m, bool unit,
+                                      T (&a)[DMAX]) {
+    T g[DMAX];
+    pot.grad(q, g);
+    if (unit) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) a[d] = -g[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) a[d] = -g[d] / m;  // src/integrator.py:73
+    }
+}
+
+template <typename T, typename Pot, int DMAX, int METHOD>
+__device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T (&p)[DMAX],
+                                                T (&v)[DMAX], T m, bool unit, T h, int L) {
+    const T h2 = h * h;
+    const T half = T(0.5);
+    T a[DMAX];
+    if (unit) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = p[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = p[d] / m;
+    }
+    if constexpr (METHOD == PBBI_LEAPFROG) {
+        accel<T, Pot, DMAX>(pot, q, m, unit, a);
+        for (int j = 0; j < L; ++j) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + (half * a[d]) * h2);
+            T an[DMAX];
+            accel<T, Pot, DMAX>(pot, q, m, unit, an);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                v[d] += (half * (a[d] + an[d])) * h;
+                a[d] = an[d];
+            }
+        }
+    } else {
+        T qpast[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) qpast[d] = q[d];
+        accel<T, Pot, DMAX>(pot, q, m, unit, a);
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) q[d] = (q[d] + v[d] * h) + (half * a[d]) * h2;
+        for (int j = 0; j < L; ++j) {
+            accel<T, Pot, DMAX>(pot, q, m, unit, a);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const T cur = q[d];
+                q[d] = (T(2) * cur - qpast[d]) + a[d] * h2;
+                qpast[d] = cur;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = (q[d] - qpast[d]) / h;
+    }
+    if (unit) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) p[d] = v[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) p[d] = v[d] * m;
+    }
+}
+
+template <typename T, typename Pot, int DMAX>
+__device__ __forceinline__ T hamiltonian(const Pot& pot, const T (&q)[DMAX], const T (&p)[DMAX],
+                                         T m) {
+    T pp = T(0);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) pp += p[d] * p[d];
+    return T(0.5) * pp / m + pot.U(q);
+}
+
+// -------------------------------------------------------------------- kernels
+template <typename T>
+struct HmcPrm {
+    const T* q_in;
+    const T* p_in;
+    const T* u_in;
+    const T* mass;
+    T* q_out;
+    T* p_out;
+    T* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    T h;
+    int L, D, flags, rng;
+    uint64_t seed, iter, chain0;
+    double kT;
+};
+
+template <typename T, typename Pot, int DMAX, int METHOD>
+__global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
+    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const bool unit = (prm.mass == nullptr);
+    const T m = unit ? T(1) : prm.mass[n];
+    const uint64_t chain = prm.chain0 + (uint64_t)n;
+    T pstd = T(1);
+    if (prm.rng) pstd = (T)sqrt((double)m * prm.kT);  // src/ensemble.py:88
+
+    T q[DMAX], p[DMAX], v[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? prm.q_in[(int64_t)d * prm.ldn_in + n] : T(0);
+    T u;
+    if (prm.rng) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            p[d] = (d < D) ? (T)(rng_normal(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, d)) * pstd
+                           : T(0);
+        u = (T)rng_uniform(prm.seed, prm.iter, chain);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            p[d] = (d < D) ? prm.p_in[(int64_t)d * prm.ldn_in + n] : T(0);
+        u = prm.u_in[n];
+    }
+    const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+    integrate_chain<T, Pot, DMAX, METHOD>(pot, q, p, v, m, unit, prm.h, prm.L);
+    const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);  // p -> -p leaves dot(p,p) unchanged
+    const T ratio = exp(oldH - newH);                        // src/HMC.py:115
+    // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
+    const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+    if (reject) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < D) q[d] = prm.q_in[(int64_t)d * prm.ldn_in + n];  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) p[d] = q[d];
+            } else if (prm.rng) {
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d)
+                    if (d < D)
+                        p[d] = (T)(rng_normal(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, d)) * pstd;
+            } else {
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d)
+                    if (d < D) p[d] = prm.p_in[(int64_t)d * prm.ldn_in + n];
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+        if (d < D) prm.q_out[(int64_t)d * prm.ldn_out + n] = q[d];
+    if (prm.p_out) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < D) prm.p_out[(int64_t)d * prm.ldn_out + n] = p[d];
+    }
+    if (prm.ratio_out) prm.ratio_out[n] = ratio;
+    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+}
+
+template <typename T>
+struct IntPrm {
+    T* q;
+    T* p;
+    const T* mass;
+    T* v_out;
+    int64_t N, ldn;
+    T h;
+    int L, D;
+};
+
+template <typename T, typename Pot, int DMAX, int METHOD>
+__global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot) {
+    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const bool unit = (prm.mass == nullptr);
+    const T m = unit ? T(1) : prm.mass[n];
+    T q[DMAX], p[DMAX], v[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        q[d] = (d < D) ? prm.q[(int64_t)d * prm.ldn + n] : T(0);
+        p[d] = (d < D) ? prm.p[(int64_t)d * prm.ldn + n] : T(0);
+    }
+    integrate_chain<T, Pot, DMAX, METHOD>(pot, q, p, v, m, unit, prm.h, prm.L);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+        if (d < D) {
+            prm.q[(int64_t)d * prm.ldn + n] = q[d];
+            prm.p[(int64_t)d * prm.ldn + n] = p[d];
+            if (prm.v_out) prm.v_out[(int64_t)d * prm.ldn + n] = v[d];
+        }
+}
+
+template <typename T>
+struct EvalPrm {
+    const T* q;
+    const T* p;
+    const T* mass;
+    T* U_out;
+    T* grad_out;
+    T* w_out;
+    int64_t N, ldn;
+    int D, mode;  // mode 0: eval (U, grad); 1: energy H/w; 2: ratio finish U_out = exp(U_out - H)
+};
+
+template <typename T, typename Pot, int DMAX>
+__global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
+    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    T q[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? prm.q[(int64_t)d * prm.ldn + n] : T(0);
+    if (prm.mode == 0) {
+        if (prm.U_out) prm.U_out[n] = pot.U(q);
+        if (prm.grad_out) {
+            T g[DMAX];
+            pot.grad(q, g);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                if (d < D) prm.grad_out[(int64_t)d * prm.ldn + n] = g[d];
+        }
+        return;
+    }
+    T p[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) p[d] = (d < D) ? prm.p[(int64_t)d * prm.ldn + n] : T(0);
+    const T m = prm.mass ? prm.mass[n] : T(1);
+    const T H = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+    if (prm.mode == 1) {
+        if (prm.U_out) prm.U_out[n] = H;
+        if (prm.w_out) prm.w_out[n] = exp(-H);  // src/HMC.py:103
+    } else {
+        prm.U_out[n] = exp(prm.U_out[n] - H);  // src/HMC.py:115
+    }
+}
+
+// ------------------------------------------------------------------- dispatch
+int pick_dmax(int D) {
+    for (int dm : {2, 4, 8, 16, 32, 64})
+        if (D <= dm) return dm;
+    return 0;
+}
+
+template <typename T, int DMAX>
+SeparablePot<T, DMAX> make_sep(const pbbi_potential* pot) {
+    return SeparablePot<T, DMAX>{(const T*)pot->d_mean, (const T*)pot->d_prec, (T)pot->cst, pot->D,
+                                 pot->kind == KIND_HARMONIC ? 1 : 0};
+}
+template <typename T, int DMAX>
+RosenbrockPot<T, DMAX> make_ros(const pbbi_potential* pot) {
+    return RosenbrockPot<T, DMAX>{(T)pot->a, (T)pot->b, (T)(1.0 / pot->s), (T)pot->cst, pot->D};
+}
+
+inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + BLOCK - 1) / BLOCK)); }
+
+#define FOR_EACH_DMAX(X) X(2) X(4) X(8) X(16) X(32) X(64)
+
+template <typename T>
+int launch_hmc(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    HmcPrm<T> prm{(const T*)a.q_in, (const T*)a.p_in, (const T*)a.u_in, (const T*)a.mass,
+                  (T*)a.q_out, (T*)a.p_out, (T*)a.ratio_out, a.reject_out,
+                  a.N, a.ldn_in, a.ldn_out, (T)a.h, a.L, pot->D, a.flags, a.rng,
+                  a.seed, a.iter, a.chain0, a.kT};
+    const int dmax = pick_dmax(pot->D);
+    const bool ros = pot->kind == KIND_ROSENBROCK;
+    const dim3 grid = grid_for(a.N);
+#define LAUNCH(DM)                                                                                 \
+    if (dmax == DM) {                                                                              \
+        if (ros) {                                                                                 \
+            auto f = make_ros<T, DM>(pot);                                                         \
+            if (a.method == PBBI_LEAPFROG)                                                         \
+                hipLaunchKernelGGL((k_lane_hmc<T, RosenbrockPot<T, DM>, DM, PBBI_LEAPFROG>), grid, \
+                                   dim3(BLOCK), 0, a.stream, prm, f);                              \
+            else                                                                                   \
+                hipLaunchKernelGGL((k_lane_hmc<T, RosenbrockPot<T, DM>, DM, PBBI_STORMER_VERLET>), \
+                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                        \
+        } else {                                                                                   \
+            auto f = make_sep<T, DM>(pot);                                                         \
+            if (a.method == PBBI_LEAPFROG)                                                         \
+                hipLaunchKernelGGL((k_lane_hmc<T, SeparablePot<T, DM>, DM, PBBI_LEAPFROG>), grid,  \
+                                   dim3(BLOCK), 0, a.stream, prm, f);                              \
+            else                                                                                   \
+                hipLaunchKernelGGL((k_lane_hmc<T, SeparablePot<T, DM>, DM, PBBI_STORMER_VERLET>),  \
+                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                        \
+        }                                                                                          \
+    }
+    FOR_EACH_DMAX(LAUNCH)
+#undef LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+template <typename T>
+int launch_integrate(const IntegrateArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    IntPrm<T> prm{(T*)a.q, (T*)a.p, (const T*)a.mass, (T*)a.v_out, a.N, a.ldn, (T)a.h, a.L, pot->D};
+    const int dmax = pick_dmax(pot->D);
+    const bool ros = pot->kind == KIND_ROSENBROCK;
+    const dim3 grid = grid_for(a.N);
+#define LAUNCH(DM)                                                                               \
+    if (dmax == DM) {                                                                            \
+        if (ros) {                                                                               \
+            auto f = make_ros<T, DM>(pot);                                                       \
+            if (a.method == PBBI_LEAPFROG)                                                       \
+                hipLaunchKernelGGL((k_lane_integrate<T, RosenbrockPot<T, DM>, DM, PBBI_LEAPFROG>), \
+                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                      \
+            else                                                                                 \
+                hipLaunchKernelGGL(                                                              \
+                    (k_lane_integrate<T, RosenbrockPot<T, DM>, DM, PBBI_STORMER_VERLET>), grid,  \
+                    dim3(BLOCK), 0, a.stream, prm, f);                                           \
+        } else {                                                                                 \
+            auto f = make_sep<T, DM>(pot);                                                       \
+            if (a.method == PBBI_LEAPFROG)                                                       \
+                hipLaunchKernelGGL((k_lane_integrate<T, SeparablePot<T, DM>, DM, PBBI_LEAPFROG>), \
+                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                      \
+            else                                                                                 \
+                hipLaunchKernelGGL(                                                              \
+                    (k_lane_integrate<T, SeparablePot<T, DM>, DM, PBBI_STORMER_VERLET>), grid,   \
+                    dim3(BLOCK), 0, a.stream, prm, f);                                           \
+        }                                                                                        \
+    }
+    FOR_EACH_DMAX(LAUNCH)
+#undef LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+template <typename T>
+int launch_eval(const EvalArgs& a, int mode) {
+    const pbbi_potential* pot = a.pot;
+    EvalPrm<T> prm{(const T*)a.q, (const T*)a.p, (const T*)a.mass, (T*)a.U_out, (T*)a.grad_out,
+                   (T*)a.w_out, a.N, a.ldn, pot->D, mode};
+    const int dmax = pick_dmax(pot->D);
+    const bool ros = pot->kind == KIND_ROSENBROCK;
+    const dim3 grid = grid_for(a.N);
+#define LAUNCH(DM)                                                                              \
+    if (dmax == DM) {                                                                           \
+        if (ros) {                                                                              \
+            auto f = make_ros<T, DM>(pot);                                                      \
+            hipLaunchKernelGGL((k_lane_eval<T, RosenbrockPot<T, DM>, DM>), grid, dim3(BLOCK), 0, \
+                               a.stream, prm, f);                                               \
+        } else {                                                                                \
+            auto f = make_sep<T, DM>(pot);                                                      \
+            hipLaunchKernelGGL((k_lane_eval<T, SeparablePot<T, DM>, DM>), grid, dim3(BLOCK), 0,  \
+                               a.stream, prm, f);                                               \
+        }                                                                                       \
+    }
+    FOR_EACH_DMAX(LAUNCH)
+#undef LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int check(const pbbi_potential* pot) {
+    if (pick_dmax(pot->D) == 0)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
+                         "chain-per-lane kernels hold D <= 64 in registers; D = " +
+                             std::to_string(pot->D) + " is not supported for this potential yet");
+    return PBBI_OK;
+}
+
+}  // namespace
+
+int lane_hmc_iter(const IterArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? launch_hmc<double>(a) : launch_hmc<float>(a);
+}
+int lane_integrate(const IntegrateArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? launch_integrate<double>(a) : launch_integrate<float>(a);
+}
+int lane_eval(const EvalArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, 0) : launch_eval<float>(a, 0);
+}
+int lane_energy(const EvalArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    const int mode = a.ratio_finish ? 2 : 1;
+    return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, mode) : launch_eval<float>(a, mode);
+}

@@ -1,0 +1,388 @@
+// pbbi_api.hip -- the extern "C" surface declared in include/pbbi.h: handle management,
+// argument checking and dispatch to the kernel translation units.  No arithmetic of the
+// hot path lives here and nothing falls back to the host.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+// ------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+
+void pbbi_set_error(const std::string& msg) { g_last_error = msg; }
+int pbbi_fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+namespace {
+
+inline size_t elem_size(int dtype) { return dtype == PBBI_F64 ? 8 : 4; }
+
+// host double -> device array of dtype
+int upload(const double* host, size_t n, int dtype, void** dev_out) {
+    *dev_out = nullptr;
+    if (n == 0) return PBBI_OK;
+    PBBI_HIP(hipMalloc(dev_out, n * elem_size(dtype)));
+    if (dtype == PBBI_F64) {
+        PBBI_HIP(hipMemcpy(*dev_out, host, n * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = (float)host[i];
+        PBBI_HIP(hipMemcpy(*dev_out, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    return PBBI_OK;
+}
+
+int new_handle(int kind, int D, int dtype, int device, pbbi_potential** out) {
+    if (!out) return pbbi_fail(PBBI_ERR_INVALID, "out pointer is NULL");
+    *out = nullptr;
+    if (D < 1) return pbbi_fail(PBBI_ERR_INVALID, "D must be >= 1");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    int count = 0;
+    PBBI_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return pbbi_fail(PBBI_ERR_INVALID, "device " + std::to_string(device) + " out of range (" +
+                                               std::to_string(count) + " HIP devices visible)");
+    pbbi_potential* p = new (std::nothrow) pbbi_potential();
+    if (!p) return pbbi_fail(PBBI_ERR_INVALID, "out of host memory");
+    p->kind = kind; p->D = D; p->dtype = dtype; p->device = device;
+    p->cst = 0.0; p->a = 1.0; p->b = 100.0; p->s = 20.0;
+    p->d_mean = p->d_prec = p->d_frag = p->d_mean_pad = nullptr;
+    p->DP = 0;
+    *out = p;
+    return PBBI_OK;
+}
+
+int finish_or_destroy(int rc, pbbi_potential** out) {
+    if (rc != PBBI_OK && out && *out) {
+        std::string keep = g_last_error;
+        pbbi_potential_destroy(*out);
+        *out = nullptr;
+        g_last_error = keep;
+    }
+    return rc;
+}
+
+int upload_mean(pbbi_potential* p, const double* mean) {
+    std::vector<double> mu((size_t)p->D, 0.0);
+    if (mean) std::memcpy(mu.data(), mean, sizeof(double) * p->D);
+    return upload(mu.data(), mu.size(), p->dtype, &p->d_mean);
+}
+
+int check_common(const pbbi_potential* pot, int64_t N, int64_t ldn) {
+    if (!pot) return pbbi_fail(PBBI_ERR_INVALID, "potential handle is NULL");
+    if (N < 0) return pbbi_fail(PBBI_ERR_INVALID, "N must be >= 0");
+    if (ldn < N) return pbbi_fail(PBBI_ERR_INVALID, "leading stride ldn must be >= N");
+    return PBBI_OK;
+}
+
+inline bool is_dense(const pbbi_potential* pot) { return pot->kind == KIND_GAUSS_DENSE; }
+
+// ---- small utility kernels ---------------------------------------------------
+template <typename T>
+__global__ void k_philox_normal(uint64_t seed, int stream, uint64_t iter, uint64_t chain0, int D,
+                                int64_t N, int64_t ldn, double scale, const T* scale_n, T* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double sc = scale_n ? (double)scale_n[n] : scale;
+    for (int d = 0; d < D; ++d)
+        out[(int64_t)d * ldn + n] = (T)(rng_normal(seed, (uint32_t)stream, iter, chain0 + n, d) * sc);
+}
+
+template <typename T>
+__global__ void k_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, T* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = (T)rng_uniform(seed, iter, chain0 + n);
+}
+
+// (S, D*N) -> (D*N, S) tiled transpose through LDS: both sides coalesced.
+template <typename T>
+__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int S, int64_t M) {
+    __shared__ T tile[32][33];
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    const int s0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int s = s0 + j;
+        const int64_t m = m0 + threadIdx.x;
+        if (s < S && m < M) tile[j][threadIdx.x] = src[(int64_t)s * M + m];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t m = m0 + j;
+        const int s = s0 + threadIdx.x;
+        if (s < S && m < M) dst[m * S + s] = tile[threadIdx.x][j];
+    }
+}
+
+}  // namespace
+
+// ======================================================================= library
+extern "C" {
+
+int pbbi_version(void) { return PBBI_VERSION; }
+
+const char* pbbi_last_error(void) { return g_last_error.c_str(); }
+
+int pbbi_device_count(int* count_out) {
+    if (!count_out) return pbbi_fail(PBBI_ERR_INVALID, "count_out is NULL");
+    *count_out = 0;
+    PBBI_HIP(hipGetDeviceCount(count_out));
+    return PBBI_OK;
+}
+
+int pbbi_device_info(int device, pbbi_devinfo* out) {
+    if (!out) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
+    hipDeviceProp_t prop;
+    PBBI_HIP(hipGetDeviceProperties(&prop, device));
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = prop.multiProcessorCount;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    out->lds_bytes_per_block = (int)prop.sharedMemPerBlock;
+    out->clock_khz = prop.clockRate;
+    return PBBI_OK;
+}
+
+// ==================================================================== potentials
+int pbbi_potential_create_harmonic(int D, const double* springConsts, int dtype, int device,
+                                   pbbi_potential** out) {
+    if (!springConsts) return pbbi_fail(PBBI_ERR_INVALID, "springConsts is NULL");
+    if (int rc = new_handle(KIND_HARMONIC, D, dtype, device, out)) return rc;
+    DeviceGuard guard(device);
+    int rc = upload(springConsts, (size_t)D, dtype, &(*out)->d_prec);
+    if (rc == PBBI_OK) rc = upload_mean(*out, nullptr);
+    return finish_or_destroy(rc, out);
+}
+
+int pbbi_potential_create_gauss_diag(int D, const double* mean, const double* prec, double cst,
+                                     int dtype, int device, pbbi_potential** out) {
+    if (!prec) return pbbi_fail(PBBI_ERR_INVALID, "prec is NULL");
+    if (int rc = new_handle(KIND_GAUSS_DIAG, D, dtype, device, out)) return rc;
+    DeviceGuard guard(device);
+    (*out)->cst = cst;
+    int rc = upload(prec, (size_t)D, dtype, &(*out)->d_prec);
+    if (rc == PBBI_OK) rc = upload_mean(*out, mean);
+    return finish_or_destroy(rc, out);
+}
+
+int pbbi_potential_create_gauss_dense(int D, const double* mean, const double* precision,
+                                      double cst, int dtype, int device, pbbi_potential** out) {
+    if (!precision) return pbbi_fail(PBBI_ERR_INVALID, "precision is NULL");
+    if (int rc = new_handle(KIND_GAUSS_DENSE, D, dtype, device, out)) return rc;
+    DeviceGuard guard(device);
+    (*out)->cst = cst;
+    int rc = upload(precision, (size_t)D * D, dtype, &(*out)->d_prec);
+    if (rc == PBBI_OK) rc = upload_mean(*out, mean);
+    if (rc == PBBI_OK) rc = dense_build_fragments(*out, precision, mean);
+    return finish_or_destroy(rc, out);
+}
+
+int pbbi_potential_create_rosenbrock(int D, double a, double b, double s, int dtype, int device,
+                                     pbbi_potential** out) {
+    if (!(s != 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "Rosenbrock scale s must be non-zero");
+    if (int rc = new_handle(KIND_ROSENBROCK, D, dtype, device, out)) return rc;
+    (*out)->a = a; (*out)->b = b; (*out)->s = s;
+    return PBBI_OK;
+}
+
+int pbbi_potential_destroy(pbbi_potential* pot) {
+    if (!pot) return PBBI_OK;
+    DeviceGuard guard(pot->device);
+    for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad})
+        if (p) (void)hipFree(p);
+    delete pot;
+    return PBBI_OK;
+}
+
+int pbbi_potential_dim(const pbbi_potential* pot) { return pot ? pot->D : PBBI_ERR_INVALID; }
+int pbbi_potential_dtype(const pbbi_potential* pot) { return pot ? pot->dtype : PBBI_ERR_INVALID; }
+int pbbi_potential_device(const pbbi_potential* pot) { return pot ? pot->device : PBBI_ERR_INVALID; }
+
+int pbbi_potential_eval(const pbbi_potential* pot, const void* q, int64_t N, int64_t ldn,
+                        void* U_out, void* grad_out, void* stream) {
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if (!q && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q is NULL");
+    DeviceGuard guard(pot->device);
+    EvalArgs a{pot, q, nullptr, nullptr, N, ldn, U_out, grad_out, nullptr, 0, (hipStream_t)stream};
+    return is_dense(pot) ? dense_eval(a) : lane_eval(a);
+}
+
+// ==================================================================== integrators
+int pbbi_integrate(const pbbi_potential* pot, int method, void* q, void* p, const void* mass,
+                   void* v_out, int64_t N, int64_t ldn, double h, int L, void* stream) {
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if (method != PBBI_LEAPFROG && method != PBBI_STORMER_VERLET)
+        return pbbi_fail(PBBI_ERR_INVALID, "Invalid integration method selected.");  // src/HMC.py:71
+    if (L < 0) return pbbi_fail(PBBI_ERR_INVALID, "numSteps must be >= 0");
+    if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
+    DeviceGuard guard(pot->device);
+    IntegrateArgs a{pot, method, q, p, mass, v_out, N, ldn, h, L, (hipStream_t)stream};
+    return is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
+}
+
+int pbbi_leapfrog(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
+                  int64_t ldn, double h, int L, void* stream) {
+    return pbbi_integrate(pot, PBBI_LEAPFROG, q, p, mass, nullptr, N, ldn, h, L, stream);
+}
+
+int pbbi_stormer_verlet(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
+                        int64_t ldn, double h, int L, void* stream) {
+    return pbbi_integrate(pot, PBBI_STORMER_VERLET, q, p, mass, nullptr, N, ldn, h, L, stream);
+}
+
+// ======================================================================= energies
+int pbbi_energy(const pbbi_potential* pot, const void* q, const void* p, const void* mass,
+                int64_t N, int64_t ldn, void* H_out, void* weight_out, void* stream) {
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
+    DeviceGuard guard(pot->device);
+    EvalArgs a{pot, q, p, mass, N, ldn, H_out, nullptr, weight_out, 0, (hipStream_t)stream};
+    return is_dense(pot) ? dense_energy(a) : lane_energy(a);
+}
+
+int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* newP,
+                       const void* oldQ, const void* oldP, const void* mass, int64_t N,
+                       int64_t ldn, void* ratio_out, void* stream) {
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if (!ratio_out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "ratio_out is NULL");
+    if ((!newQ || !newP || !oldQ || !oldP) && N > 0)
+        return pbbi_fail(PBBI_ERR_INVALID, "a state pointer is NULL");
+    DeviceGuard guard(pot->device);
+    // pass 1: ratio_out <- oldH ; pass 2: ratio_out <- exp(ratio_out - newH)   (src/HMC.py:109-115)
+    EvalArgs a{pot, oldQ, oldP, mass, N, ldn, ratio_out, nullptr, nullptr, 0, (hipStream_t)stream};
+    if (int rc = is_dense(pot) ? dense_energy(a) : lane_energy(a)) return rc;
+    EvalArgs b{pot, newQ, newP, mass, N, ldn, ratio_out, nullptr, nullptr, 1, (hipStream_t)stream};
+    return is_dense(pot) ? dense_energy(b) : lane_energy(b);
+}
+
+// ================================================================ HMC iteration(s)
+static int hmc_check(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L) {
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if (method != PBBI_LEAPFROG && method != PBBI_STORMER_VERLET)
+        return pbbi_fail(PBBI_ERR_INVALID, "Invalid integration method selected.");
+    if (L < 0) return pbbi_fail(PBBI_ERR_INVALID, "numSteps must be >= 0");
+    return PBBI_OK;
+}
+
+int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                  const void* u_in, const void* mass, void* q_out, void* p_out, void* ratio_out,
+                  uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags,
+                  void* stream) {
+    if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    if ((!q_in || !p_in || !u_in || !q_out) && N > 0)
+        return pbbi_fail(PBBI_ERR_INVALID, "q_in / p_in / u_in / q_out must be non-NULL");
+    DeviceGuard guard(pot->device);
+    IterArgs a{};
+    a.pot = pot; a.method = method; a.q_in = q_in; a.p_in = p_in; a.u_in = u_in; a.mass = mass;
+    a.q_out = q_out; a.p_out = p_out; a.ratio_out = ratio_out; a.reject_out = reject_out;
+    a.N = N; a.ldn_in = ldn; a.ldn_out = ldn; a.h = h; a.L = L; a.flags = flags;
+    a.rng = 0; a.kT = 1.0; a.stream = (hipStream_t)stream;
+    return is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
+}
+
+int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
+                 void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
+                 int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
+                 uint64_t iter0, uint64_t chain0, double kT, void* stream) {
+    if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    if (S < 0) return pbbi_fail(PBBI_ERR_INVALID, "S must be >= 0");
+    if ((!q_state || !samples_out) && N > 0 && S > 0)
+        return pbbi_fail(PBBI_ERR_INVALID, "q_state / samples_out must be non-NULL");
+    if (!(kT >= 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be >= 0");
+    if (S == 0 || N == 0) return PBBI_OK;
+    DeviceGuard guard(pot->device);
+    const size_t es = elem_size(pot->dtype);
+    const size_t slab = (size_t)pot->D * (size_t)N;  // elements per (D, N) sample slab
+    for (int i = 0; i < S; ++i) {
+        IterArgs a{};
+        a.pot = pot; a.method = method; a.mass = mass;
+        // iteration i reads the state left by iteration i-1: the previous sample slab
+        a.q_in = (i == 0) ? q_state : (const char*)samples_out + (size_t)(i - 1) * slab * es;
+        a.ldn_in = (i == 0) ? ldn : N;
+        a.q_out = (char*)samples_out + (size_t)i * slab * es;
+        a.p_out = momenta_out ? (char*)momenta_out + (size_t)i * slab * es : nullptr;
+        a.ldn_out = N;
+        a.ratio_out = ratio_out ? (char*)ratio_out + (size_t)i * N * es : nullptr;
+        a.reject_out = reject_out ? reject_out + (size_t)i * N : nullptr;
+        a.N = N; a.h = h; a.L = L; a.flags = flags;
+        a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
+        a.stream = (hipStream_t)stream;
+        if (int rc = is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a)) return rc;
+    }
+    // leave the chain state in q_state (strided D2D copy of the last slab)
+    PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * es,
+                              (const char*)samples_out + (size_t)(S - 1) * slab * es, (size_t)N * es,
+                              (size_t)N * es, (size_t)pot->D, hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+    return PBBI_OK;
+}
+
+// ============================================================================ RNG
+int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t chain0, int D,
+                       int64_t N, int64_t ldn, double scale, const void* scale_per_chain,
+                       int dtype, int device, void* out, void* stream) {
+    if (D < 1 || N < 0 || ldn < N) return pbbi_fail(PBBI_ERR_INVALID, "bad D / N / ldn");
+    if (!out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
+    if (N == 0) return PBBI_OK;
+    DeviceGuard guard(device);
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_philox_normal<double>, grid, block, 0, (hipStream_t)stream, seed,
+                           rng_stream, iter, chain0, D, N, ldn, scale,
+                           (const double*)scale_per_chain, (double*)out);
+    else if (dtype == PBBI_F32)
+        hipLaunchKernelGGL(k_philox_normal<float>, grid, block, 0, (hipStream_t)stream, seed,
+                           rng_stream, iter, chain0, D, N, ldn, scale, (const float*)scale_per_chain,
+                           (float*)out);
+    else
+        return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int pbbi_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int dtype,
+                        int device, void* out, void* stream) {
+    if (N < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad N");
+    if (!out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
+    if (N == 0) return PBBI_OK;
+    DeviceGuard guard(device);
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_philox_uniform<double>, grid, block, 0, (hipStream_t)stream, seed, iter,
+                           chain0, N, (double*)out);
+    else if (dtype == PBBI_F32)
+        hipLaunchKernelGGL(k_philox_uniform<float>, grid, block, 0, (hipStream_t)stream, seed, iter,
+                           chain0, N, (float*)out);
+    else
+        return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// ========================================================================= layout
+int pbbi_transpose_sdn_to_dns(const void* src_sdn, void* dst_dns, int S, int D, int64_t N,
+                              int dtype, int device, void* stream) {
+    if (S < 0 || D < 1 || N < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad S / D / N");
+    if (S == 0 || N == 0) return PBBI_OK;
+    if (!src_sdn || !dst_dns) return pbbi_fail(PBBI_ERR_INVALID, "src / dst is NULL");
+    DeviceGuard guard(device);
+    const int64_t M = (int64_t)D * N;
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((S + 31) / 32)), block(32, 8);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_transpose<double>, grid, block, 0, (hipStream_t)stream,
+                           (const double*)src_sdn, (double*)dst_dns, S, M);
+    else if (dtype == PBBI_F32)
+        hipLaunchKernelGGL(k_transpose<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float*)src_sdn, (float*)dst_dns, S, M);
+    else
+        return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+}  // extern "C"

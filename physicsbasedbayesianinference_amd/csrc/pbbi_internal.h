@@ -1,0 +1,108 @@
+// pbbi_internal.h -- shared between the translation units of libpbbi.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "pbbi.h"
+
+enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3 };
+
+struct pbbi_potential {
+    int kind;
+    int D;
+    int dtype;
+    int device;
+    double cst, a, b, s;
+    void* d_mean;  // D elements (dtype) or nullptr
+    void* d_prec;  // D elements (harmonic / diag) or D*D row-major (dense)
+    // dense Gaussian, register-resident MFMA path (D <= 128):
+    int DP;        // D padded to a multiple of 16 (0 = path not available)
+    void* d_frag;  // DP*DP elements: precision in MFMA A-fragment order
+    void* d_mean_pad;  // DP elements, zero padded
+};
+
+// ---- error plumbing ---------------------------------------------------------
+void pbbi_set_error(const std::string& msg);
+int pbbi_fail(int code, const std::string& msg);
+
+#define PBBI_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return pbbi_fail(PBBI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct DeviceGuard {  // make the handle's device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---- launch descriptors passed between api and kernel TUs ---------------------
+struct IterArgs {
+    const pbbi_potential* pot;
+    int method;
+    const void* q_in;
+    const void* p_in;  // nullptr in RNG mode
+    const void* u_in;  // nullptr in RNG mode
+    const void* mass;
+    void* q_out;
+    void* p_out;
+    void* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    double h;
+    int L;
+    int flags;
+    // RNG mode
+    int rng;
+    uint64_t seed, iter, chain0;
+    double kT;
+    hipStream_t stream;
+};
+
+struct IntegrateArgs {
+    const pbbi_potential* pot;
+    int method;
+    void* q;
+    void* p;
+    const void* mass;
+    void* v_out;
+    int64_t N, ldn;
+    double h;
+    int L;
+    hipStream_t stream;
+};
+
+struct EvalArgs {
+    const pbbi_potential* pot;
+    const void* q;
+    const void* p;     // energy only
+    const void* mass;  // energy only
+    int64_t N, ldn;
+    void* U_out;     // potential (eval) or H (energy)
+    void* grad_out;  // eval only
+    void* w_out;     // energy only: exp(-H)
+    int ratio_finish;  // energy only: U_out[n] = exp(U_out[n] - H)   (src/HMC.py:115)
+    hipStream_t stream;
+};
+
+// chain-per-lane kernels (harmonic / diagonal Gaussian / Rosenbrock), kernels_lane.hip
+int lane_hmc_iter(const IterArgs& a);
+int lane_integrate(const IntegrateArgs& a);
+int lane_eval(const EvalArgs& a);
+int lane_energy(const EvalArgs& a);
+// dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
+int dense_hmc_iter(const IterArgs& a);
+int dense_integrate(const IntegrateArgs& a);
+int dense_eval(const EvalArgs& a);
+int dense_energy(const EvalArgs& a);
+int dense_build_fragments(pbbi_potential* pot, const double* precision_host, const double* mean_host);

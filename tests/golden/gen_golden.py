@@ -15,7 +15,7 @@ form (the reference's tests use jax autodiff, which is unavailable offline):
   std / diagonal Gaussian   U = 0.5*sum(prec*(q-mu)^2) + c      dU = prec*(q-mu)
   dense Gaussian            U = 0.5*(q-mu).P.(q-mu) + c         dU = P.(q-mu)
   harmonic                  U = reference harmonicPotentialND   dU = k*q
-  Rosenbrock                U = sum_i [b(q_{i+1}-q_i^2)^2 + (a-q_i)^2]/s
+  Rosenbrock                U = sum_i [b(q_{i+1}-q_i^2)^2 + (a-q_i)^2] * (1/s)
 Fixture list mirrors SURVEY.md section 8c (G1..G10) plus two extras (G11, G12).
 """
 import io
@@ -72,15 +72,17 @@ def harmonic(k):
 
 
 def rosenbrock(a=1.0, b=100.0, s=20.0):
+    inv_s = 1.0 / s  # the build's definition scales by the pre-computed reciprocal
+
     def U(q):
         t = q[1:] - q[:-1] ** 2
-        return (np.sum(b * t * t) + np.sum((a - q[:-1]) ** 2)) / s
+        return (np.sum(b * t * t) + np.sum((a - q[:-1]) ** 2)) * inv_s
 
     def dU(q):
         g = np.zeros_like(q)
         t = q[1:] - q[:-1] ** 2
-        g[:-1] += (-4.0 * b * q[:-1] * t - 2.0 * (a - q[:-1])) / s
-        g[1:] += (2.0 * b * t) / s
+        g[:-1] += (-4.0 * b * q[:-1] * t - 2.0 * (a - q[:-1])) * inv_s
+        g[1:] += (2.0 * b * t) * inv_s
         return g
 
     return U, dU

@@ -1,0 +1,377 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI
+(include/pbbi.h via physicsbasedbayesianinference_amd._lib), against
+  (1) the golden vectors recorded from the reference's own Python, and
+  (2) the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64):
+  chain-per-lane kernels (harmonic / diagonal Gaussian / Rosenbrock) keep the
+    oracle's operation order exactly -> q, p BIT-EXACT vs the oracle, 1e-12 vs golden;
+  dense-Gaussian MFMA kernel sums dot products in a different order (k-ordered
+    MFMA chain + lane butterfly) -> RTOL_DENSE = 1e-11 scaled by max|ref|;
+  reject masks: EQUAL in every case (the fixtures hold no |u - ratio| tie).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.constants import k as kB
+
+from conftest import load_golden
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL_GOLDEN = 1e-12
+RTOL_DENSE = 1e-11
+
+
+@pytest.fixture(scope="module")
+def P():
+    import physicsbasedbayesianinference_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from physicsbasedbayesianinference_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def scaled_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+    inf = np.isinf(a) | np.isinf(b)
+    assert np.array_equal(a[inf], b[inf]), "inf pattern differs"
+    ok = ~(np.isnan(a) | inf)
+    if not ok.any():
+        return 0.0
+    return float(np.max(np.abs(a[ok] - b[ok]))) / max(1.0, float(np.max(np.abs(b[ok]))))
+
+
+def make_pot(P, g, kind):
+    if kind == "dense":
+        return P.GaussianDense(g["mean"], precision=g["precision"], const=float(g["const"]))
+    if kind == "std":
+        return P.StandardGaussian(int(g["D"]))
+    if kind == "rosenbrock":
+        return P.Rosenbrock(int(g["D"]), float(g["a"]), float(g["b"]), float(g["s"]))
+    raise KeyError(kind)
+
+
+def orc_pot(g, kind):
+    if kind == "dense":
+        return orc.pot_gauss_dense(g["mean"], g["precision"], float(g["const"]))
+    if kind == "std":
+        return orc.pot_gauss_diag(np.zeros(int(g["D"])), np.ones(int(g["D"])))
+    return orc.pot_rosenbrock(int(g["D"]), float(g["a"]), float(g["b"]), float(g["s"]))
+
+
+def gpu_hmc_iter(lib, pot, method, q, p, u, mass, h, L, compat=True):
+    """One pbbi_hmc_iter call on host arrays; returns q_out, p_out, ratio, reject."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    D, N = q.shape
+    dev = pot.device
+    qd, pd, ud = (as_device(x, dev, np.float64) for x in (q, p, u))
+    md = None if mass is None or np.all(np.asarray(mass) == 1.0) else as_device(mass, dev, np.float64)
+    qo, po = empty((D, N), np.float64, dev), empty((D, N), np.float64, dev)
+    ro, rj = empty((N,), np.float64, dev), empty((N,), np.uint8, dev)
+    lib.call("pbbi_hmc_iter", pot.handle, orc.METHODS[method], qd.data_ptr(), pd.data_ptr(),
+             ud.data_ptr(), md.data_ptr() if md is not None else None, qo.data_ptr(), po.data_ptr(),
+             ro.data_ptr(), rj.data_ptr(), N, N, float(h), int(L),
+             lib.COMPAT_P_FROM_OLDQ if compat else 0, stream_ptr(dev))
+    torch.cuda.synchronize()
+    return to_numpy(qo), to_numpy(po), to_numpy(ro), to_numpy(rj).astype(bool)
+
+
+GETSAMPLES = [
+    ("G3_getsamples_c1", "std", True),
+    ("G4_getsamples_dense_d8", "dense", False),
+    ("G4_getsamples_dense_d128", "dense", False),
+    ("G4b_getsamples_dense_mean_d16", "dense", False),
+    ("G5_getsamples_rosenbrock_d32", "rosenbrock", True),
+    ("G6_getsamples_rejects", "std", True),
+    ("G7_getsamples_nan", "std", True),
+    ("G8_getsamples_mass", "dense", False),
+    ("G11_getsamples_test2", "dense", False),
+    ("G12_getsamples_stormerverlet", "dense", False),
+]
+
+
+@pytest.mark.parametrize("name,kind,exact", GETSAMPLES)
+def test_hmc_iter_vs_golden_and_oracle(P, lib, name, kind, exact):
+    g = load_golden(name)
+    pot, opot = make_pot(P, g, kind), orc_pot(g, kind)
+    S, L, h, method = int(g["S"]), int(g["numSteps"]), float(g["stepSize"]), str(g["method"])
+    q = np.ascontiguousarray(g["q0"])
+    for i in range(S):
+        p, u = np.ascontiguousarray(g["p_draw"][i]), g["u"][i]
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, g["mass"], h, L)
+        # --- vs the reference's own run
+        assert np.array_equal(rej, g["reject_mask"][i]), f"{name} it {i}: reject mask differs"
+        tol = RTOL_GOLDEN if exact else RTOL_DENSE
+        assert scaled_err(qo, g["samples"][:, :, i]) <= tol
+        assert scaled_err(po, g["momenta"][:, :, i]) <= tol
+        # --- vs the oracle on the same inputs
+        q_or, p_or = q.copy(), p.copy()
+        r_or, rej_or = orc.hmc_iter(opot, method, q_or, p_or, u, g["mass"], h, L)
+        assert np.array_equal(rej, rej_or)
+        if exact:
+            assert np.array_equal(qo, q_or, equal_nan=True) and np.array_equal(po, p_or, equal_nan=True)
+        else:
+            assert scaled_err(qo, q_or) <= RTOL_DENSE and scaled_err(po, p_or) <= RTOL_DENSE
+        fin = np.isfinite(r_or) & (r_or > 0) & np.isfinite(ratio) & (ratio > 0)
+        assert np.array_equal(np.isnan(ratio), np.isnan(r_or))
+        if fin.any():
+            assert np.max(np.abs(np.log(ratio[fin]) - np.log(r_or[fin]))) < 1e-8
+        q = qo
+
+
+@pytest.mark.parametrize("name,kind,exact", GETSAMPLES)
+def test_getsamples_class_api_vs_golden(P, name, kind, exact):
+    """The drop-in class API on the reference's seed: HMC(...).getSamples(...)."""
+    g = load_golden(name)
+    D, N, S = int(g["D"]), int(g["N"]), int(g["S"])
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(D, N)
+    ens.mass = g["mass"].copy()
+    pot = make_pot(P, g, kind)
+    hmc = P.HMC(ens, float(g["simulTime"]), float(g["stepSize"]), None, potential=pot,
+                method=str(g["method"]), verbose=False)
+    assert hmc.integrator.numSteps == int(g["numSteps"])
+    samples, momenta = hmc.getSamples(S, float(g["temperature"]), float(g["qStd"]))
+    assert samples.shape == (D, N, S) and momenta.shape == (D, N, S)
+    assert samples.dtype == np.float64
+    assert np.array_equal(hmc.reject_masks, g["reject_mask"])
+    tol = RTOL_GOLDEN if exact else RTOL_DENSE
+    assert scaled_err(samples, g["samples"]) <= tol
+    assert scaled_err(momenta, g["momenta"]) <= tol
+    # aliasing after getSamples (src/HMC.py:148): integrator.q is ensemble.q = last sample
+    assert hmc.integrator.q is ens.q
+    assert scaled_err(ens.q, g["samples"][:, :, -1]) <= tol
+
+
+INTEG = [
+    ("G1_leapfrog_harmonic", "Leapfrog", ("_h0.1", "_h0.01")),
+    ("G2_stormerverlet_harmonic", "Stormer-Verlet", ("_h0.1", "_h0.01")),
+    ("G8b_leapfrog_mass", "Leapfrog", ("",)),
+    ("G8c_stormerverlet_mass", "Stormer-Verlet", ("",)),
+]
+
+
+@pytest.mark.parametrize("name,method,sfxs", INTEG)
+def test_integrator_classes_harmonic(P, name, method, sfxs):
+    g = load_golden(name)
+    pot = P.Harmonic(g["springConsts"])
+    cls = P.Leapfrog if method == "Leapfrog" else P.StormerVerlet
+    for s in sfxs:
+        D, N = g["q0" + s].shape
+        ens = P.Ensemble(D, N)
+        ens.mass = g["mass" + s].copy()
+        ens.q[...] = g["q0" + s]
+        ens.p[...] = g["p0" + s]
+        integ = cls(ens, float(g["stepSize" + s]), float(g["finalTime" + s]), pot.gradient)
+        assert integ.numSteps == int(g["numSteps" + s])
+        q, p = integ.integrate()
+        assert q is ens.q and p is ens.p  # in place and aliased (src/integrator.py:123)
+        assert scaled_err(q, g["q" + s]) <= RTOL_GOLDEN
+        assert scaled_err(p, g["p" + s]) <= RTOL_GOLDEN
+        assert scaled_err(integ.v, g["v" + s]) <= RTOL_GOLDEN
+        # bit-exact vs the oracle
+        qo, po = np.ascontiguousarray(g["q0" + s]), np.ascontiguousarray(g["p0" + s])
+        vo = orc.integrate(orc.pot_harmonic(g["springConsts"]), method, qo, po, g["mass" + s],
+                           float(g["stepSize" + s]), int(g["numSteps" + s]))
+        assert np.array_equal(q, qo) and np.array_equal(p, po) and np.array_equal(integ.v, vo)
+
+
+def test_leapfrog_rosenbrock_vs_golden(P):
+    g = load_golden("G5b_leapfrog_rosenbrock_d32")
+    pot = P.Rosenbrock(32, float(g["a"]), float(g["b"]), float(g["s"]))
+    ens = P.Ensemble(32, int(g["N"]))
+    ens.q[...] = g["q0"]
+    ens.p[...] = g["p0"]
+    q, p = P.Leapfrog(ens, float(g["stepSize"]), float(g["finalTime"]), pot).integrate()
+    assert scaled_err(q, g["q"]) <= RTOL_GOLDEN and scaled_err(p, g["p"]) <= RTOL_GOLDEN
+
+
+@pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
+@pytest.mark.parametrize("D", [8, 32, 100, 128])
+def test_dense_integrate_vs_oracle(P, D, method):
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    mu = rs.standard_normal(D)
+    N = 70  # ragged: 4 full 16-chain tiles + 6
+    mass = 1.0 + (np.arange(N) % 3) * 0.5
+    pot = P.GaussianDense(mu, precision=Pm, const=0.0)
+    for m in (None, mass):
+        ens = P.Ensemble(D, N)
+        if m is not None:
+            ens.mass = m.copy()
+        ens.q[...] = rs.standard_normal((D, N)) * 2
+        ens.p[...] = rs.standard_normal((D, N))
+        qo, po = ens.q.copy(), ens.p.copy()
+        cls = P.Leapfrog if method == "Leapfrog" else P.StormerVerlet
+        integ = cls(ens, 0.1, 1.0, pot.gradient)
+        q, p = integ.integrate()
+        vo = orc.integrate(orc.pot_gauss_dense(mu, Pm), method, qo, po, m, 0.1, 10)
+        assert scaled_err(q, qo) <= RTOL_DENSE and scaled_err(p, po) <= RTOL_DENSE
+        assert scaled_err(integ.v, vo) <= RTOL_DENSE
+
+
+def test_dense_matvec_layout_with_asymmetric_matrix(P):
+    """A symmetric precision would hide a transposed A-fragment map (cdna guide: 'A=I check
+    with ASYMMETRIC B'); feed a deliberately non-symmetric matrix straight to the handle."""
+    D, N = 128, 33
+    rs = np.random.RandomState(1)
+    M = rs.standard_normal((D, D))
+    mu = rs.standard_normal(D)
+    pot = P.GaussianDense(mu, precision=M, const=0.25, symmetrize=False)
+    q = rs.standard_normal((D, N))
+    U, g = pot.value_and_gradient(q)
+    g_ref = M @ (q - mu[:, None])
+    U_ref = 0.5 * np.sum((q - mu[:, None]) * g_ref, axis=0) + 0.25
+    assert scaled_err(g, g_ref) <= 1e-13
+    assert scaled_err(U, U_ref) <= 1e-13
+    Uo, go = orc.potential(orc.pot_gauss_dense(mu, M, 0.25), q, want_grad=True)
+    assert scaled_err(g, go) <= 1e-13 and scaled_err(U, Uo) <= 1e-13
+
+
+def test_known_answers(P):
+    g = load_golden("G10_known_answers")
+    # src/tests/test_potential.py:13-25: harmonic potential at (3, 4) with k = (2, 3) is 33
+    U = P.harmonicPotentialND(g["harmonic_q"], g["harmonic_k"])
+    assert U[0] == 33.0
+    assert np.array_equal(U, g["harmonic_U"])
+    assert P.harmonicPotentialND(np.array([3.0, 4.0]), np.array([2, 3])) == 33.0
+
+
+@pytest.mark.parametrize("kind,D", [("harmonic", 1), ("harmonic", 3), ("diag", 5), ("diag", 33),
+                                     ("rosenbrock", 2), ("rosenbrock", 7), ("rosenbrock", 32),
+                                     ("rosenbrock", 40)])
+def test_potential_eval_bitexact_vs_oracle(P, kind, D):
+    rs = np.random.RandomState(D)
+    q = rs.standard_normal((D, 257))
+    if kind == "harmonic":
+        k = rs.uniform(0.5, 3, D)
+        pot, op = P.Harmonic(k), orc.pot_harmonic(k)
+    elif kind == "diag":
+        mu, prec = rs.standard_normal(D), rs.uniform(0.5, 3, D)
+        pot, op = P.GaussianDiag(mu, prec=prec, const=0.5), orc.pot_gauss_diag(mu, prec, 0.5)
+    else:
+        pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    U, g = pot.value_and_gradient(q)
+    Uo, go = orc.potential(op, q, want_grad=True)
+    assert np.array_equal(U, Uo) and np.array_equal(g, go)
+    # (D,) calling convention of the reference
+    assert pot(q[:, 3]) == Uo[3] and np.array_equal(pot.gradient(q[:, 3]), go[:, 3])
+
+
+def test_weights_and_ratio_api(P):
+    g = load_golden("G4_getsamples_dense_d8")
+    pot = make_pot(P, g, "dense")
+    ens = P.Ensemble(8, int(g["N"]))
+    hmc = P.HMC(ens, 1.0, 0.1, None, potential=pot, verbose=False)
+    newQ, newP = g["q_prop"][0], -g["p_prop"][0]
+    r = hmc.getWeightsRatio(newQ, newP, g["q0"], g["p_draw"][0])
+    assert np.max(np.abs(np.log(r) - np.log(g["ratio"][0]))) < 1e-9
+    w = hmc.getWeights(g["q0"], g["p_draw"][0])
+    wo, Ho = orc.weights(orc_pot(g, "dense"), np.ascontiguousarray(g["q0"]),
+                         np.ascontiguousarray(g["p_draw"][0]))
+    assert np.max(np.abs(np.log(w) + Ho)) < 1e-9
+
+
+# ------------------------------------------------------------------------ Philox
+def test_philox_device_matches_oracle(lib):
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr, to_numpy
+    D, N = 19, 1000
+    out = empty((D, N), np.float64, 0)
+    lib.call("pbbi_philox_normal", 77, lib.STREAM_MOMENTUM, 3, 123456789012, D, N, N, 1.5, None,
+             lib.F64, 0, out.data_ptr(), stream_ptr(0))
+    z = to_numpy(out)
+    zo = orc.philox_normal(77, orc.STREAM_MOMENTUM, 3, 123456789012, D, N, 1.5)
+    assert np.max(np.abs(z - zo)) < 1e-14  # transcendental part: device vs host libm
+    u = empty((N,), np.float64, 0)
+    lib.call("pbbi_philox_uniform", 77, 3, 5, N, lib.F64, 0, u.data_ptr(), stream_ptr(0))
+    assert np.array_equal(to_numpy(u), orc.philox_uniform(77, 3, 5, N))  # integer part: bit-exact
+
+
+@pytest.mark.parametrize("kind,D,N", [("std", 1, 32), ("rosenbrock", 32, 200), ("dense", 128, 150),
+                                       ("dense", 24, 64)])
+def test_hmc_run_philox_vs_oracle(P, kind, D, N):
+    S, L, h = 4, 10, 0.1 if kind != "rosenbrock" else 0.01
+    if kind == "dense":
+        rs = np.random.RandomState(D)
+        A = rs.standard_normal((D, D))
+        Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+        Pm = 0.5 * (Pm + Pm.T)
+        pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
+    elif kind == "std":
+        pot, op = P.StandardGaussian(D), orc.pot_gauss_diag(np.zeros(D), np.ones(D))
+    else:
+        pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=2024, verbose=False)
+    assert hmc.integrator.numSteps == L
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.7, chain0=1000)
+    q = orc.philox_normal(2024, orc.STREAM_POSITION, 0, 1000, D, N, 0.7)
+    so, mo, rej, ratio = orc.hmc_run_philox(op, "Leapfrog", q, None, h, L, S, seed=2024, chain0=1000)
+    assert np.array_equal(hmc.reject_masks, rej)
+    assert scaled_err(samples, np.transpose(so, (1, 2, 0))) <= RTOL_DENSE
+    assert scaled_err(momenta, np.transpose(mo, (1, 2, 0))) <= RTOL_DENSE
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_tiny_ensembles(P):
+    pot = P.StandardGaussian(2)
+    for N in (0, 1):
+        np.random.seed(0)
+        ens = P.Ensemble(2, N)
+        s, m = P.HMC(ens, 1.0, 0.1, None, potential=pot, verbose=False).getSamples(3, 1 / kB, 1.0)
+        assert s.shape == (2, N, 3) and m.shape == (2, N, 3)
+    s, m = P.HMC(P.Ensemble(2, 5), 1.0, 0.1, None, potential=pot, verbose=False).getSamples(
+        0, 1 / kB, 1.0)
+    assert s.shape == (2, 5, 0)
+
+
+def test_zero_steps_keeps_state(P):
+    """numSteps = int(0.05/0.1) = 0: nothing moves, ratio == 1, nothing rejected."""
+    pot = P.StandardGaussian(3)
+    np.random.seed(3)
+    ens = P.Ensemble(3, 40)
+    hmc = P.HMC(ens, 0.05, 0.1, None, potential=pot, verbose=False)
+    assert hmc.integrator.numSteps == 0
+    s, m = hmc.getSamples(2, 1 / kB, 1.0)
+    assert np.array_equal(s[:, :, 0], s[:, :, 1]) and not hmc.reject_masks.any()
+    assert np.all(hmc.ratios == 1.0)
+
+
+def test_noncompat_rejected_momentum_is_the_draw(P, lib):
+    g = load_golden("G6_getsamples_rejects")
+    pot = make_pot(P, g, "std")
+    q, p, u = g["q0"], g["p_draw"][0], g["u"][0]
+    qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, None, 1.5, 2, compat=False)
+    assert rej.sum() > 50
+    assert np.array_equal(po[:, rej], p[:, rej]) and np.array_equal(qo[:, rej], q[:, rej])
+    qc, pc, _, rejc = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, None, 1.5, 2, compat=True)
+    assert np.array_equal(rej, rejc) and np.array_equal(pc[:, rej], q[:, rej])
+    assert np.array_equal(po[:, ~rej], pc[:, ~rej])
+
+
+def test_error_behaviour(P, lib):
+    pot = P.StandardGaussian(2)
+    ens = P.Ensemble(2, 4)
+    with pytest.raises(ValueError, match="Invalid integration method selected."):
+        P.HMC(ens, 1.0, 0.1, None, potential=pot, method="Euler")       # src/HMC.py:70-71
+    with pytest.raises(TypeError):
+        P.HMC(ens, 1.0, 0.1, None, potential=lambda q: 0.5 * q @ q)      # no host fallback
+    with pytest.raises(NotImplementedError):
+        P.Integrator(ens, 0.1, 1.0, pot.gradient).integrate()           # src/integrator.py:87-91
+    with pytest.raises(IndexError):
+        ens.particle(5)                                                 # src/ensemble.py:102-107
+    big = P.Harmonic(np.ones(65))  # chain-per-lane kernels hold D <= 64
+    with pytest.raises(lib.PbbiError):
+        big(np.zeros(65))
