@@ -72,6 +72,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -m physicsbasedbayesianinference_amd.build); this package has no CPU fallback")
+    # Bind to the SAME HIP runtime instance as PyTorch (our device-buffer plumbing): torch ships
+    # its own libamdhip64.so.7; importing it first makes the loader resolve libpbbi.so's
+    # dependency to that already-loaded copy instead of mapping a second runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table drift apart
