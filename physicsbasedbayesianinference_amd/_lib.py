@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbbi.so")
+# PBBI_LIB: load another build of the same ABI (diagnostic builds, e.g. tools/stamp_probe.py)
+LIB_PATH = os.environ.get("PBBI_LIB") or os.path.join(_HERE, "libpbbi.so")
 
 OK = 0
 F64, F32 = 0, 1

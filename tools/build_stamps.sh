@@ -1,0 +1,12 @@
+#!/bin/bash
+# Diagnostic build of libpbbi with in-kernel s_memtime stamps (see tools/stamp_probe.py).
+set -e
+cd "$(dirname "$0")/.."
+C=physicsbasedbayesianinference_amd/csrc
+make -C $C -j3 >/dev/null
+mkdir -p build/stamps
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -DPBBI_STAMPS \
+    -c $C/kernels_dense.hip -o build/stamps/kernels_dense.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/stamps/libpbbi_stamps.so \
+    $C/pbbi_api.o $C/kernels_lane.o build/stamps/kernels_dense.o
+echo build/stamps/libpbbi_stamps.so
