@@ -34,13 +34,18 @@
  *   counter = (chain_lo32, block, iteration_lo32, stream | chain_hi24 << 8),
  *   where `chain` is the GLOBAL chain index (chain0 + n), so results do not
  *   depend on how the ensemble is sharded over GPUs.
- *   Standard normal of element (dim, chain): block = ((dim>>3)<<2) | (dim&3);
- *     u1 = (((x1:x0)>>11)+1) * 2^-53 in (0,1],  u2 = ((x3:x2)>>11) * 2^-53,
- *     r = sqrt(-2 ln u1);  z = r*cospi(2 u2) if bit 2 of dim is 0 else r*sinpi(2 u2).
+ *   Standard normals: one block serves the four dims d, d+4, d+8, d+12 of a group of 16
+ *     (block = ((dim>>4)<<2) | (dim&3), slot = (dim>>2)&3) through two SINGLE-PRECISION
+ *     Box-Muller transforms, (x0,x1) -> slots 0,1 and (x2,x3) -> slots 2,3:
+ *       u1 = a*2^-32 + 2^-33 in (0,1],  u2 = (b>>8)*2^-24,  r = sqrtf(-2 ln u1),
+ *       z_even = r*cos(2 pi u2),  z_odd = r*sin(2 pi u2),  widened to the array dtype.
+ *     The device evaluates log2/sqrt/sin/cos on its transcendental unit; draws are
+ *     reproducible bit for bit on the device (pbbi_philox_normal returns exactly what
+ *     pbbi_hmc_run draws), exact N(0,1) on a 2^-24-relative grid with tails to 6.7 sigma.
  *   Metropolis uniform of a chain: block = 0xFFFFFFFF, stream = PBBI_STREAM_UNIFORM,
  *     u = ((x1:x0)>>11) * 2^-53 in [0,1).
- *   The integer part is bit-identical to oracle/pbbi_oracle.c; the
- *   transcendental part agrees to a few ulp (device libm vs host libm).
+ *   The integer part is bit-identical to oracle/pbbi_oracle.c; the single-precision
+ *   transcendental part agrees with the host mirror to ~1e-6 absolute.
  */
 #ifndef PBBI_H
 #define PBBI_H

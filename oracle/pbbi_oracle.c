@@ -407,34 +407,30 @@ static double u53(uint32_t lo, uint32_t hi) { /* [0,1) with 53 random bits */
     return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53;
 }
 
-/* sin(pi x), cos(pi x) for x in [0,2): exact octant reduction, then libm */
-static void sincospi_02(double x, double* s, double* c) {
-    const double PI = 3.14159265358979323846;
-    double sgn_s = 1.0, sgn_c = 1.0;
-    if (x >= 1.0) { x -= 1.0; sgn_s = -1.0; sgn_c = -1.0; } /* sin(pi(x+1)) = -sin, cos = -cos */
-    if (x > 0.5) { x = 1.0 - x; sgn_c = -sgn_c; }          /* reflect about 1/2             */
-    if (x > 0.25) { /* use co-function for accuracy near pi/2 */
-        const double y = 0.5 - x;
-        *s = sgn_s * cos(PI * y);
-        *c = sgn_c * sin(PI * y);
-    } else {
-        *s = sgn_s * sin(PI * x);
-        *c = sgn_c * cos(PI * x);
-    }
+/* Single-precision Box-Muller on 2 x 32 bits (host mirror of csrc/pbbi_rng.h::box_muller_f32).
+ *   u1 = a*2^-32 + 2^-33 in (0,1],  u2 = (b>>8)*2^-24 in [0,1),  r = sqrt(-2 ln 2 * log2(u1)).
+ * The device evaluates log2/sqrt/sin/cos on its transcendental unit (v_log_f32, ...); this
+ * mirror uses libm's float functions, so the two agree to ~1e-6 absolute, not bitwise. */
+static void box_muller_f32(uint32_t a, uint32_t b, float* zc, float* zs) {
+    const float u1 = fmaf((float)a, 0x1.0p-32f, 0x1.0p-33f);
+    const float u2 = (float)(b >> 8) * 0x1.0p-24f;
+    const float r = sqrtf(-1.3862943611198906f * log2f(u1));
+    const double ang = 6.283185307179586476925 * (double)u2;
+    *zc = r * (float)cos(ang);
+    *zs = r * (float)sin(ang);
 }
 
 /* standard normal for element (dim, chain) of draw `iter` in `stream`:
- *   block index blk = ((dim >> 3) << 2) | (dim & 3); dims d and d^4 share a block,
- *   bit 2 of dim selects the Box-Muller branch (0: cos, 1: sin). */
+ *   block index blk = ((dim >> 4) << 2) | (dim & 3): dims d, d+4, d+8, d+12 (same d mod 4
+ *   inside a group of 16) share a block; slot = (dim >> 2) & 3 picks
+ *   0: r1 cos, 1: r1 sin  (from x0, x1);  2: r2 cos, 3: r2 sin  (from x2, x3). */
 static double rng_normal(uint64_t seed, uint32_t stream, uint64_t iter, uint64_t chain, int dim) {
     uint32_t x[4];
-    rng_block(seed, stream, iter, chain, (uint32_t)(((dim >> 3) << 2) | (dim & 3)), x);
-    const double u1 = (double)(((((uint64_t)x[1] << 32) | x[0]) >> 11) + 1) * 0x1.0p-53; /* (0,1] */
-    const double u2 = u53(x[2], x[3]);
-    const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi_02(2.0 * u2, &s, &c);
-    return ((dim >> 2) & 1) ? r * s : r * c;
+    float z[4];
+    rng_block(seed, stream, iter, chain, (uint32_t)(((dim >> 4) << 2) | (dim & 3)), x);
+    box_muller_f32(x[0], x[1], &z[0], &z[1]);
+    box_muller_f32(x[2], x[3], &z[2], &z[3]);
+    return (double)z[(dim >> 2) & 3];
 }
 
 static double rng_uniform(uint64_t seed, uint64_t iter, uint64_t chain) {

@@ -43,8 +43,8 @@ constexpr int CHAINS_PER_WAVE = 16;
 constexpr int CHAINS_PER_WG = 64;
 
 #ifdef PBBI_STAMPS
-// Diagnostic build only (make EXTRA=-DPBBI_STAMPS): s_memtime stamps of the phases of
-// k_dense_leapfrog2, written to a buffer of their own (tools/stamp_probe.py).  Never quote
+// Diagnostic build only (tools/build_stamps.sh): s_memtime stamps of the phases of
+// k_dense_hmc, written to a buffer of their own (tools/stamp_probe.py).  Never quote
 // the run time of such a build; read the SHARES.
 static unsigned long long* g_stamp_buf = nullptr;
 extern "C" void pbbi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
@@ -234,13 +234,12 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
         if (prm.rng) {
             const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
 #pragma unroll
-            for (int s = 0; s < KS; s += 2) {
-                double zc, zs;
-                rng_normal_pair(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain,
-                                (uint32_t)(((s >> 1) << 2) | g), zc, zs);
-                v[s] = (FULL || 4 * s + g < D) ? zc * pstd : 0.0;
-                v[s + 1] = (FULL || 4 * (s + 1) + g < D) ? zs * pstd : 0.0;
-                __builtin_amdgcn_sched_barrier(0);  // one Philox/Box-Muller body at a time
+            for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g
+                float z[4];
+                rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl)
+                    v[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? (double)z[sl] * pstd : 0.0;
             }
             u = rng_uniform(prm.seed, prm.iter, chain);
             if (have_pout && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid) {
@@ -379,307 +378,42 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused leapfrog (v2): every per-element update runs in the shadow of the MFMA stream.
-//
-// A wave has ONE instruction stream (one wave per SIMD), and a 64-cycle f64 MFMA only lets
-// ~14 other instructions issue behind it.  v1 above does "update all 32 elements, then 256
-// MFMAs back to back": the VALU block and the matrix pipe never overlap (measured: MFMA pipe
-// 50 % busy).  Here the leapfrog update of element s+1 is computed WHILE the 8 MFMAs of
-// K-step s execute, which is legal because K-step s of the mat-vec only needs x_s:
-//
-//   region s:   ds_read A-fragments(s+1), mu(s+1)
-//               x_{s+1} <- finish v (deferred half of the previous step), advance q   [VALU]
-//               8 x MFMA( A(s), x_s ) -> accN                                        [MFMA]
-//   interleaved by sched_group_barrier as 1 MFMA : 2 VALU.
-//
-// The velocity update of step j needs the gradient of step j, which is complete only after the
-// whole mat-vec; it is therefore deferred into the regions of step j+1 (MODE 2), reading the
-// finished accumulator accP while the new one, accN, fills (two accumulator sets, ping-pong).
-// In RNG mode the Philox/Box-Muller momentum draw is injected into the regions of the initial
-// mat-vec (MODE 0), which does not depend on p.  Arithmetic per element is unchanged from the
-// kick-drift-kick leapfrog (algebraically the reference's update, see v3 below) with
-// a = -(g * (1/m)) in place of -g/m for non-unit masses.
-// ------------------------------------------------------------------------------------------
-struct StepCtx {
-    double h, h2, m, minv;
-    bool unit;
-};
-
-struct RngCtx {
-    uint64_t seed, iter, chain;
-    double pstd;
-    int g, D;
-};
-
-// Kick-drift-kick form (see the v3 comment below for the algebra): state is q and the
-// half-step velocity vh only.
-// MODE 0: x = q - mu (initial gradient).
-// MODE 1: first step: vh = p/m + (0.5*a_0)*h, drift.   MODE 2: vh += a_j*h, drift.
-template <int NT, int MODE>
-__device__ __forceinline__ double next_x(int s, double mu_s, double (&q)[4 * NT],
-                                         double (&vh)[4 * NT], const v4f64 (&accP)[NT],
-                                         const StepCtx& c) {
-    if constexpr (MODE != 0) {
-        const double an = -(accP[s >> 2][s & 3] * c.minv);  // getAccel  (:61-73)
-        if constexpr (MODE == 1) {
-            if (!c.unit) vh[s] = vh[s] / c.m;  // v = p/m  (:106)
-            vh[s] += (0.5 * an) * c.h;         // first half kick
-        } else {
-            vh[s] += an * c.h;                 // full kick
-        }
-        q[s] += vh[s] * c.h;                   // drift
-    }
-    return q[s] - mu_s;
-}
-
-template <int NT, int MODE, bool RNG, bool FULL>
-__device__ __forceinline__ void fused_matvec(const v2f64* __restrict__ fragL,
-                                             const double* __restrict__ muG,
-                                             double (&q)[4 * NT], double (&v)[4 * NT],
-                                             const v4f64 (&accP)[NT], v4f64 (&accN)[NT],
-                                             const StepCtx& c, const RngCtx& rc) {
-    constexpr int KS = 4 * NT;
-    constexpr int H = NT / 2;
-    v2f64 A[H], An[H];
-#pragma unroll
-    for (int t2 = 0; t2 < H; ++t2) A[t2] = fragL[t2 * 64];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) accN[t] = v4f64{0.0, 0.0, 0.0, 0.0};
-    double x = next_x<NT, MODE>(0, muG[0], q, v, accP, c);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        double xn = 0.0;
-        if (s + 1 < KS) {
-#pragma unroll
-            for (int t2 = 0; t2 < H; ++t2) An[t2] = fragL[((s + 1) * H + t2) * 64];
-            xn = next_x<NT, MODE>(s + 1, muG[4 * (s + 1)], q, v, accP, c);
-        }
-        if (RNG && (s & 1) == 0) {  // momentum pair (s, s+1): dims 4s+g and 4s+4+g share a block
-            double zc, zs;
-            rng_normal_pair(rc.seed, PBBI_STREAM_MOMENTUM, rc.iter, rc.chain,
-                            (uint32_t)(((s >> 1) << 2) | rc.g), zc, zs);
-            v[s] = (FULL || 4 * s + rc.g < rc.D) ? zc * rc.pstd : 0.0;
-            v[s + 1] = (FULL || 4 * (s + 1) + rc.g < rc.D) ? zs * rc.pstd : 0.0;
-        }
-#pragma unroll
-        for (int t2 = 0; t2 < H; ++t2) {
-            accN[2 * t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].x, x, accN[2 * t2], 0, 0, 0);
-            accN[2 * t2 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].y, x, accN[2 * t2 + 1], 0, 0, 0);
-        }
-        // shape of the region: LDS reads first, then one MFMA followed by a few VALU, NT times
-        __builtin_amdgcn_sched_group_barrier(0x100, H + 1, 0);
-        if (RNG && (s & 1) == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 1 : 2, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t2 = 0; t2 < H; ++t2) A[t2] = An[t2];
-        x = xn;
-    }
-}
-
-template <int NT, bool FULL>
-__global__ void __launch_bounds__(BLOCK, 1) k_dense_leapfrog(DensePrm prm) {
-    constexpr int DP = 16 * NT;
-    constexpr int KS = 4 * NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    v2f64* frag2 = reinterpret_cast<v2f64*>(smem);
-    double* mu = reinterpret_cast<double*>(smem + (size_t)DP * DP * sizeof(double));
-    stage_lds<NT>(prm.frag, prm.mu, frag2, mu);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4;
-    const int c = lane & 15;
-    const v2f64* fragL = frag2 + lane;
-    const double* muG = mu + g;
-    const int D = prm.D;
-    const bool unit = (prm.mass == nullptr);
-    const int64_t n_wg_tiles = (prm.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG;
-
-    for (int64_t wt = blockIdx.x; wt < n_wg_tiles; wt += gridDim.x) {
-        const int64_t n0 = (wt * 4 + wave) * CHAINS_PER_WAVE;  // wave-uniform
-        if (n0 >= prm.N) continue;
-        const int64_t left = prm.N - n0;
-        const bool valid = c < left;
-        const int cc = valid ? c : (int)left - 1;  // ragged tail: compute on a clamped chain
-        // byte offsets for the buffer accesses (pbbi_buf.h)
-        const uint32_t ld_in = 8u * (uint32_t)prm.ldn_in, ld_out = 8u * (uint32_t)prm.ldn_out;
-        const uint32_t vin = (uint32_t)g * ld_in + 8u * (uint32_t)cc, s4in = 4u * ld_in;
-        const uint32_t vout = (uint32_t)g * ld_out + 8u * (uint32_t)cc, s4out = 4u * ld_out;
-        const __amdgpu_buffer_rsrc_t qin = buf_make(prm.q_in + n0);
-        const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
-        const __amdgpu_buffer_rsrc_t qout = buf_make(prm.q_out + n0);
-        const __amdgpu_buffer_rsrc_t pout = buf_make(prm.p_out + n0);
-        const bool have_pout = (prm.p_out != nullptr);
-        const double m = unit ? 1.0 : prm.mass[n0 + cc];
-        const StepCtx sc{prm.h, prm.h * prm.h, m, unit ? 1.0 : 1.0 / m, unit};
-        RngCtx rc{prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc), 0.0, g, D};
-
-        // ---- momentum: rolled Philox loop through the momentum slab (see v3), then q
-        double u = 0.0;
-        __amdgpu_buffer_rsrc_t psrc = pin;
-        uint32_t vp = vin, s4p = s4in, ldp = ld_in;
-        if (prm.rng) {
-            rc.pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
-#pragma unroll 1
-            for (int k = 0; k < KS / 2; ++k) {
-                double zc, zs;
-                rng_normal_pair(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, rc.chain,
-                                (uint32_t)((k << 2) | g), zc, zs);
-                if (FULL || 8 * k + g < D) buf_store(pout, vout, (uint32_t)(2 * k) * s4out, zc * rc.pstd);
-                if (FULL || 8 * k + 4 + g < D)
-                    buf_store(pout, vout, (uint32_t)(2 * k + 1) * s4out, zs * rc.pstd);
-            }
-            u = rng_uniform(prm.seed, prm.iter, rc.chain);
-            psrc = pout;
-            vp = vout; s4p = s4out; ldp = ld_out;
-        } else if (prm.mode == 0) {
-            u = prm.u_in[n0 + cc];
-        }
-        double q[KS], v[KS];  // v: p, then the half-step velocity, then p again
-        v4f64 accA[NT], accB[NT];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) v[s] = load_elem<FULL>(psrc, vp, s4p, ldp, s, g, D);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
-        fused_matvec<NT, 0, false, FULL>(fragL, muG, q, v, accB, accA, sc, rc);  // g(q0) -> accA
-        double pp_old = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) pp_old += v[s] * v[s];
-        double xg_old = dot_x_acc<NT>(muG, q, accA);
-        double xg_new = xg_old, pp_new = pp_old;
-
-        if (prm.L > 0) {
-            fused_matvec<NT, 1, false, FULL>(fragL, muG, q, v, accA, accB, sc, rc);  // -> accB
-            int j = 1;
-            for (; j + 1 < prm.L; j += 2) {
-                fused_matvec<NT, 2, false, FULL>(fragL, muG, q, v, accB, accA, sc, rc);
-                fused_matvec<NT, 2, false, FULL>(fragL, muG, q, v, accA, accB, sc, rc);
-            }
-            if (j < prm.L) {
-                fused_matvec<NT, 2, false, FULL>(fragL, muG, q, v, accB, accA, sc, rc);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) accB[t] = accA[t];
-            }
-            // accB = g(q_L): last half kick, p = v*m (:119), U(q_L) from the same mat-vec
-            xg_new = dot_x_acc<NT>(muG, q, accB);
-            pp_new = 0.0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = 4 * t + r;
-                    v[s] += (0.5 * -(accB[t][r] * sc.minv)) * sc.h;
-                    if (prm.mode == 0) {
-                        v[s] = unit ? v[s] : v[s] * m;
-                        pp_new += v[s] * v[s];
-                    }
-                }
-        } else if (prm.mode == 1 && !unit) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) v[s] = v[s] / m;
-        }
-        // from here on v holds the momentum p (mode 0) or the velocity v_L (mode 1)
-
-        if (prm.mode == 1) {  // integrate(): in place q, p; optional Integrator.v
-            const __amdgpu_buffer_rsrc_t vout_p = buf_make(prm.v_out + n0);
-            if (valid) {
-                if (prm.v_out) {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) store_elem<FULL>(vout_p, vout, s4out, s, g, D, v[s]);
-                }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);
-                    store_elem<FULL>(pout, vout, s4out, s, g, D, unit ? v[s] : v[s] * m);
-                }
-            }
-            continue;
-        }
-
-        // ---- energies, ratio, decision (src/HMC.py:109-115,166-173)
-        pp_old = chain_sum(pp_old);
-        pp_new = chain_sum(pp_new);
-        xg_old = chain_sum(xg_old);
-        xg_new = chain_sum(xg_new);
-        const double oldH = 0.5 * pp_old / m + (0.5 * xg_old + prm.cst);
-        const double newH = 0.5 * pp_new / m + (0.5 * xg_new + prm.cst);
-        const double ratio = exp(oldH - newH);
-        const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
-        const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
-        bool store_p = have_pout;
-        if (reject) {  // rare: fetch the old point again instead of keeping 64 more VGPRs live
-#pragma unroll
-            for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);  // :175
-            if (compat) {  // :176  p <- oldQ
-#pragma unroll
-                for (int s = 0; s < KS; ++s) v[s] = q[s];
-            } else if (prm.rng) {
-                store_p = false;  // the parked draw stays
-            } else if (have_pout) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) v[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);  // :178
-            if (store_p) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, v[s]);  // :179
-            }
-        }
-        if (valid && g == 0) {
-            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
-            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Leapfrog v3: two waves per SIMD.
+// k_dense_hmc: the production leapfrog path (L >= 1).  Two waves per SIMD.
 //
 // The f64 MFMA pipe is per SIMD; one wave alone cannot keep it busy while it also runs the
-// leapfrog bookkeeping (v1: 50 % busy).  Instead of hand-interleaving one instruction stream,
-// put TWO waves on every SIMD and let the hardware overlap one wave's VALU / memory phases
-// with the other wave's MFMAs.  That needs a workgroup of 512 threads (8 waves share the one
-// 129 KiB LDS image of P) and a wave that fits in 256 registers, which the reference's
-// velocity-Verlet form (q, v, a + accumulator = 256 registers of state alone) does not.
-// The same integrator in kick-drift-kick form needs only q and the half-step velocity:
-//     vh_0     = v_0 + (0.5*a_0)*h                       (first half kick)
-//     q_{j+1}  = q_j + vh_j*h                            (drift)           [in the MFMA regions]
-//     vh_{j+1} = vh_j + a_{j+1}*h                        (full kick)
-//     v_L      = vh_{L-1} + (0.5*a_L)*h                  (last half kick)
-// which is algebraically identical to src/integrator.py:112-117 (q += v*h + 0.5*a*h**2;
-// v += 0.5*(a+a')*h) and differs from it by rounding only (a few ulp per step; the dense path
-// is tolerance-checked against the oracle in any case because of the MFMA summation order).
-// State per wave: q (64 VGPR) + vh (64 VGPR) + accumulator (64 AGPR) + A fragments.
+// leapfrog bookkeeping, the momentum draw and its loads/stores (k_dense_traj above: matrix
+// pipe 50 % busy).  Two waves per SIMD let the hardware overlap one wave's VALU / memory
+// phases with the other wave's MFMAs.  That needs a workgroup of 512 threads (8 waves share
+// the one 129 KiB LDS image of P) and a wave that fits in 256 registers -- which the
+// reference's velocity-Verlet form (q, v, a + accumulator = 256 registers of state alone)
+// does not.  Three measures make it fit, each verified against the ISA / on the GPU:
+//   1. Kick-drift-kick form: state is q and the half-step velocity vh only,
+//        vh_0     = v_0 + (0.5*a_0)*h          q_{j+1} = q_j + vh_j*h
+//        vh_{j+1} = vh_j + a_{j+1}*h           v_L     = vh_{L-1} + (0.5*a_L)*h
+//      algebraically identical to src/integrator.py:112-117 (q += v*h + 0.5*a*h**2;
+//      v += 0.5*(a+a')*h), different by rounding only (a few ulp per step; the dense path is
+//      tolerance-checked in any case because of the MFMA summation order).  Masses enter as
+//      v = p*(1/m), a = -(g*(1/m)) (exact for the reference's default unit masses).
+//   2. The 128 output rows of each mat-vec are produced in two PASSES of 64 rows, so the live
+//      accumulator is 32 registers, not 64; same MFMA count, x_s is simply formed twice.
+//   3. One 128-chain tile per workgroup, no persistent loop, no run-time branches around the
+//      register arrays, buffer (SRSRC) addressing: in a loop hipcc hoists every loop-invariant
+//      (~60 fp64 polynomial constants of log/sincospi/exp, all row offsets) and keeps them
+//      live for the whole kernel (~140 VGPRs); branches around array updates double the
+//      arrays through phi copies; flat addressing costs one 64-bit VGPR address per row.
+// The momentum draw is a ROLLED Philox/Box-Muller loop that writes the momentum slab, which
+// the lane then reads back exactly like an uploaded p_in (unrolled into registers the 16
+// inlined bodies spill hundreds of VGPRs).
 // ------------------------------------------------------------------------------------------
 constexpr int BLOCK2 = 512;
 constexpr int CHAINS_PER_WG2 = 128;
 
-// One PASS of the mat-vec: row tiles [PASS*NTP, (PASS+1)*NTP) of G = P X, i.e. NTP*16 output
-// rows, over all K-steps.  Splitting the 128 output rows into two passes halves the live
-// accumulator (32 instead of 64 registers) so that q + vh + acc + fragments fit the
-// 256-register budget of two waves per SIMD without spills; the MFMA count is unchanged and
-// the B operand x_s = q_s - mu_s is simply formed once per pass.
+// One PASS of the mat-vec: row tiles [PASS*NTP, (PASS+1)*NTP) of G = P X over all K-steps.
 // DRIFT (first pass of a step only): q[s] += vh[s]*h just before element s feeds its K-step.
 // ONE set of A fragments, each pair reloaded for the next K-step right after the two MFMAs
 // that consumed it; the next x is formed in the shadow of the current K-step's MFMAs.
-template <int NT, int NTP, int PASS, bool DRIFT>
+// ZMEAN: mu == 0, x_s is q_s itself (no LDS read, no subtraction).  The drift is one fma.
+template <int NT, int NTP, int PASS, bool DRIFT, bool ZMEAN>
 __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
                                             const double* __restrict__ muG, double (&q)[4 * NT],
                                             const double (&vh)[4 * NT], v4f64 (&acc)[NTP],
@@ -693,8 +427,8 @@ __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
     for (int t2 = 0; t2 < HP; ++t2) A[t2] = fragL[(T0 + t2) * 64];
 #pragma unroll
     for (int t = 0; t < NTP; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
-    if constexpr (DRIFT) q[0] += vh[0] * h;
-    double x = q[0] - muG[0];
+    if constexpr (DRIFT) q[0] = fma(vh[0], h, q[0]);
+    double x = ZMEAN ? q[0] : q[0] - muG[0];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -705,16 +439,16 @@ __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
         }
         double xn = 0.0;
         if (s + 1 < KS) {
-            if constexpr (DRIFT) q[s + 1] += vh[s + 1] * h;
-            xn = q[s + 1] - muG[4 * (s + 1)];
+            if constexpr (DRIFT) q[s + 1] = fma(vh[s + 1], h, q[s + 1]);
+            xn = ZMEAN ? q[s + 1] : q[s + 1] - muG[4 * (s + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
         x = xn;
     }
 }
 
-// sum over this pass's rows of x * g  (rows 16*(PASS*NTP + t) + 4r + g  <->  s = 4*(PASS*NTP+t)+r)
-template <int NT, int NTP, int PASS>
+// sum over this pass's rows of x * g   (s = 4*(PASS*NTP + t) + r)
+template <int NT, int NTP, int PASS, bool ZMEAN>
 __device__ __forceinline__ double dot_pass(const double* __restrict__ muG,
                                            const double (&q)[4 * NT], const v4f64 (&acc)[NTP]) {
     double sum = 0.0;
@@ -723,38 +457,34 @@ __device__ __forceinline__ double dot_pass(const double* __restrict__ muG,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s = 4 * (PASS * NTP + t) + r;
-            sum += (q[s] - muG[4 * s]) * acc[t][r];
+            sum = fma(ZMEAN ? q[s] : q[s] - muG[4 * s], acc[t][r], sum);
         }
     return sum;
 }
 
-// vh[s] += (-(g_s * minv)) * hk for this pass's rows; FIRST also applies v = p/m beforehand.
-template <int NT, int NTP, int PASS, bool FIRST>
-__device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&acc)[NTP],
-                                          double minv, double hk, bool unit, double m) {
-    if constexpr (FIRST) {
-        if (!unit) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vh[4 * (PASS * NTP + t) + r] /= m;  // v = p/m (:106)
-        }
-    }
+// vh[s] += a_s * hk with a_s = -g_s/m: one fma per element, ck = hk/m
+template <int NT, int NTP, int PASS>
+__device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&acc)[NTP], double ck) {
 #pragma unroll
     for (int t = 0; t < NTP; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vh[4 * (PASS * NTP + t) + r] += (-(acc[t][r] * minv)) * hk;
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * (PASS * NTP + t) + r;
+            vh[s] = fma(-acc[t][r], ck, vh[s]);
+        }
 }
 
-template <int NT, bool FULL>
-__global__ void __launch_bounds__(BLOCK2, 2) k_dense_leapfrog2(DensePrm prm) {
+// MODE 0: one HMC iteration (src/HMC.py:154-179).  MODE 1: integrate() in place.
+template <int NT, bool FULL, int MODE, bool ZMEAN>
+__global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
+    constexpr int NPASS = NT >= 4 ? 2 : 1;  // row passes per mat-vec
+    constexpr int NTP = NT / NPASS;         // row tiles per pass (even)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef PBBI_STAMPS
-    const int lane0_ = threadIdx.x & 63, wave0_ = threadIdx.x >> 6;
-    { const int lane = lane0_, wave = wave0_; STAMP(0); }
-#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    STAMP(0);
     v2f64* frag2 = reinterpret_cast<v2f64*>(smem);
     double* mu = reinterpret_cast<double*>(smem + (size_t)DP * DP * sizeof(double));
     {
@@ -763,13 +493,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_leapfrog2(DensePrm prm) {
         for (int i = threadIdx.x; i < DP; i += BLOCK2) mu[i] = prm.mu[i];
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Static priority for one of the two waves that share a SIMD (waves w and w+4): left at
-    // equal priority the pair runs in lockstep -- both in their VALU/memory phases at the same
-    // time, matrix pipe idle (measured 62 % busy).  With waves 0-3 at priority 1 the favoured
-    // wave streams its MFMAs as if alone and its partner's MFMAs fill every gap it leaves,
-    // while the partner's own VALU work issues underneath the favoured wave's MFMAs.
+    // Static priority for one of the two waves that share a SIMD (waves w and w+4).
     if (wave < 4) __builtin_amdgcn_s_setprio(1);
     STAMP(1);
     const int g = lane >> 4;
@@ -777,146 +501,131 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_leapfrog2(DensePrm prm) {
     const v2f64* fragL = frag2 + lane;
     const double* muG = mu + g;
     const int D = prm.D;
-    const bool unit = (prm.mass == nullptr);
     const double h = prm.h;
-    // One 128-chain tile per workgroup, NOT a persistent grid-stride loop: inside a loop hipcc
-    // hoists every loop-invariant (the ~60 fp64 polynomial constants of log/sincospi/exp, all
-    // row offsets) out of it and keeps them live in registers for the whole kernel -- measured
-    // ~140 VGPRs of dead weight, i.e. spills at the 256-register budget.  Re-staging P from L2
-    // once per tile costs ~1 % of the tile's MFMA time.
-    {
-        const int64_t wt = blockIdx.x;
-        const int64_t n0 = (wt * 8 + wave) * CHAINS_PER_WAVE;  // wave-uniform
-        if (n0 >= prm.N) return;
-        const int64_t left = prm.N - n0;
-        const bool valid = c < left;
-        const int cc = valid ? c : (int)left - 1;  // ragged tail: compute on a clamped chain
-        // byte offsets for the buffer accesses (pbbi_buf.h)
-        const uint32_t ld_in = 8u * (uint32_t)prm.ldn_in, ld_out = 8u * (uint32_t)prm.ldn_out;
-        const uint32_t vin = (uint32_t)g * ld_in + 8u * (uint32_t)cc, s4in = 4u * ld_in;
-        const uint32_t vout = (uint32_t)g * ld_out + 8u * (uint32_t)cc, s4out = 4u * ld_out;
-        const __amdgpu_buffer_rsrc_t qin = buf_make(prm.q_in + n0);
-        const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
-        const __amdgpu_buffer_rsrc_t qout = buf_make(prm.q_out + n0);
-        const __amdgpu_buffer_rsrc_t pout = buf_make(prm.p_out + n0);
-        const bool have_pout = (prm.p_out != nullptr);
-        const double m = unit ? 1.0 : prm.mass[n0 + cc];
-        const double minv = unit ? 1.0 : 1.0 / m;
+
+    const int64_t n0 = ((int64_t)blockIdx.x * 8 + wave) * CHAINS_PER_WAVE;  // wave-uniform
+    if (n0 >= prm.N) return;
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;  // ragged tail: compute on a clamped chain
+    // byte offsets for the buffer accesses (pbbi_buf.h)
+    const uint32_t ld_in = 8u * (uint32_t)prm.ldn_in, ld_out = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vin = (uint32_t)g * ld_in + 8u * (uint32_t)cc, s4in = 4u * ld_in;
+    const uint32_t vout = (uint32_t)g * ld_out + 8u * (uint32_t)cc, s4out = 4u * ld_out;
+    const __amdgpu_buffer_rsrc_t qin = buf_make(prm.q_in + n0);
+    const __amdgpu_buffer_rsrc_t qout = buf_make(prm.q_out + n0);
+    const __amdgpu_buffer_rsrc_t pout = buf_make(prm.p_out + n0);
+    const double m = prm.mass ? prm.mass[n0 + cc] : 1.0;
+    const double minv = prm.mass ? 1.0 / m : 1.0;
+    const bool rng = (MODE == 0) && prm.rng;
+
+    // ---- momentum: one Philox block per 4 rows (RNG mode) or the uploaded p_in, then q
+    double q[KS], vh[KS];
+    v4f64 acc[NTP];
+    if (rng) {
         const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
-
-        // ---- momentum.  RNG mode: a rolled loop (one Philox/Box-Muller body, few registers)
-        //      writes the draw into the momentum slab, which this lane then reads back like
-        //      an uploaded p_in; unrolled into registers the 16 inlined bodies spill hundreds
-        //      of VGPRs.  Clamped (ragged-tail) lanes write the same value to the same address.
-        double u = 0.0;
-        __amdgpu_buffer_rsrc_t psrc = pin;
-        uint32_t vp = vin, s4p = s4in, ldp = ld_in;
-        if (prm.rng) {
-            const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
-#pragma unroll 1
-            for (int k = 0; k < KS / 2; ++k) {  // pair k: rows 8k+g and 8k+4+g share a block
-                double zc, zs;
-                rng_normal_pair(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain,
-                                (uint32_t)((k << 2) | g), zc, zs);
-                if (FULL || 8 * k + g < D) buf_store(pout, vout, (uint32_t)(2 * k) * s4out, zc * pstd);
-                if (FULL || 8 * k + 4 + g < D)
-                    buf_store(pout, vout, (uint32_t)(2 * k + 1) * s4out, zs * pstd);
-            }
-            u = rng_uniform(prm.seed, prm.iter, chain);
-            STAMP(2);
-            psrc = pout;
-            vp = vout; s4p = s4out; ldp = ld_out;
-        } else if (prm.mode == 0) {
-            u = prm.u_in[n0 + cc];
+        const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
+#pragma unroll
+        for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g, slot = 0..3
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                vh[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? (double)z[sl] * pstd : 0.0;
         }
-        constexpr int NPASS = NT >= 4 ? 2 : 1;  // row passes per mat-vec
-        constexpr int NTP = NT / NPASS;         // row tiles per pass (even)
-        double q[KS], vh[KS];
-        v4f64 acc[NTP];
+        if (prm.p_out && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid) {
+            // non-compat: a rejected chain reports its drawn momentum; park the draw in the slab
+            // now (accepted chains overwrite it below) rather than regenerate it later.
 #pragma unroll
-        for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(psrc, vp, s4p, ldp, s, g, D);
+            for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, vh[s]);
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
-        double pp_old = 0.0;
+        for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
+    }
+    STAMP(2);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) pp_old += vh[s] * vh[s];
+    for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+    __builtin_amdgcn_sched_barrier(0);
+    double pp = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        pp += vh[s] * vh[s];
+        vh[s] *= minv;  // v = p/m  (:106), as p*(1/m)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);
 
-        STAMP(3);
-        // ---- g(q_0) in two row passes: U(q_old), then the first half kick (if L > 0)
-        const bool go = prm.L > 0;
-        const double h0 = go ? 0.5 * h : 0.0;  // first kick is a half kick
-        matvec_pass<NT, NTP, 0, false>(fragL, muG, q, vh, acc, h);
-        double xg = dot_pass<NT, NTP, 0>(muG, q, acc);
-        if (go) kick_pass<NT, NTP, 0, true>(vh, acc, minv, h0, unit, m);
+    // ---- g(q_0) in row passes: U(q_old) and the first half kick
+    const double ck = h * minv, ckh = 0.5 * ck;  // kick coefficients h/m and h/(2m)
+    matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+    double xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+    kick_pass<NT, NTP, 0>(vh, acc, ckh);
+    if constexpr (NPASS == 2) {
+        matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+        xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+        kick_pass<NT, NTP, 1>(vh, acc, ckh);
+    }
+    // H(q_old, p_old) now, so that only one double stays live across the trajectory
+    const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
+    STAMP(4);
+    xg = 0.0;
+    for (int j = 0; j < prm.L; ++j) {
+        const bool last = (j == prm.L - 1);
+        const double cj = last ? ckh : ck;  // the last kick is a half kick
+        STAMP(5 + 2 * j);
+        matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, h);  // drift + g(q_{j+1})
+        if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+        kick_pass<NT, NTP, 0>(vh, acc, cj);
+        STAMP(6 + 2 * j);
         if constexpr (NPASS == 2) {
-            matvec_pass<NT, NTP, 1, false>(fragL, muG, q, vh, acc, h);
-            xg += dot_pass<NT, NTP, 1>(muG, q, acc);
-            if (go) kick_pass<NT, NTP, 1, true>(vh, acc, minv, h0, unit, m);
+            matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+            if (last && MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+            kick_pass<NT, NTP, 1>(vh, acc, cj);
         }
-        // H(q_old, p_old) now, so that only one double stays live across the trajectory
-        const double oldH = 0.5 * chain_sum(pp_old) / m + (0.5 * chain_sum(xg) + prm.cst);
-        double newH = oldH;
-        STAMP(4);
-        if (go) {
-            for (int j = 0; j < prm.L; ++j) {
-                STAMP(5 + 2 * j);
-                const bool last = (j == prm.L - 1);
-                const double hk = last ? 0.5 * h : h;  // last kick is a half kick
-                matvec_pass<NT, NTP, 0, true>(fragL, muG, q, vh, acc, h);  // drift + g(q_{j+1})
-                if (last) xg = dot_pass<NT, NTP, 0>(muG, q, acc);
-                kick_pass<NT, NTP, 0, false>(vh, acc, minv, hk, unit, m);
-                STAMP(6 + 2 * j);
-                if constexpr (NPASS == 2) {
-                    matvec_pass<NT, NTP, 1, false>(fragL, muG, q, vh, acc, h);
-                    if (last) xg += dot_pass<NT, NTP, 1>(muG, q, acc);
-                    kick_pass<NT, NTP, 1, false>(vh, acc, minv, hk, unit, m);
-                }
-            }
-            if (prm.mode == 0) {  // U(q_new) from g(q_L); p = v*m (:119), vh now holds p
-                double pp_new = 0.0;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    vh[s] = unit ? vh[s] : vh[s] * m;
-                    pp_new += vh[s] * vh[s];
-                }
-                newH = 0.5 * chain_sum(pp_new) / m + (0.5 * chain_sum(xg) + prm.cst);
-            }
-        } else if (!unit && prm.mode == 1) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) vh[s] = vh[s] / m;
-        }
+    }
+    // vh = v_L, xg = x_L . g(q_L)
 
-        if (prm.mode == 1) {  // integrate(): in place q, p; optional Integrator.v  (vh = v_L)
-            const __amdgpu_buffer_rsrc_t vout_p = buf_make(prm.v_out + n0);
-            if (valid) {
-                if (prm.v_out) {
+    if constexpr (MODE == 1) {  // integrate(): in place q, p; optional Integrator.v
+        const __amdgpu_buffer_rsrc_t vout_p = buf_make(prm.v_out + n0);
+        if (valid) {
+            if (prm.v_out) {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) store_elem<FULL>(vout_p, vout, s4out, s, g, D, vh[s]);
-                }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);
-                    store_elem<FULL>(pout, vout, s4out, s, g, D, unit ? vh[s] : vh[s] * m);
-                }
+                for (int s = 0; s < KS; ++s) store_elem<FULL>(vout_p, vout, s4out, s, g, D, vh[s]);
             }
-            return;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);
+                store_elem<FULL>(pout, vout, s4out, s, g, D, vh[s] * m);  // p = v*m (:119)
+            }
         }
-
+    } else {
+        // ---- energies, ratio, decision (src/HMC.py:109-115,166-173)
+        pp = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            vh[s] *= m;  // p = v*m  (:119); vh now holds p
+            pp += vh[s] * vh[s];
+        }
+        const double newH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
         STAMP(40);
-        // ---- ratio, decision (src/HMC.py:115,166-173)
         const double ratio = exp(oldH - newH);
+        const double u = rng ? rng_uniform(prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc))
+                             : prm.u_in[n0 + cc];
         const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
         const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
-        bool store_p = have_pout;
+        bool store_p = (prm.p_out != nullptr);
         if (reject) {  // rare: fetch the old point again instead of keeping it in registers
 #pragma unroll
             for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);  // :175
             if (compat) {  // :176  p <- oldQ
 #pragma unroll
                 for (int s = 0; s < KS; ++s) vh[s] = q[s];
-            } else if (prm.rng) {
-                store_p = false;  // the parked draw stays
-            } else if (have_pout) {
+            } else if (rng) {
+                store_p = false;  // the draw parked in the slab stays
+            } else if (store_p) {
+                const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
             }
@@ -1048,41 +757,35 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
     const size_t lds = lds_bytes(pot->DP);
     const dim3 grid(grid_size(pot, N)), block(BLOCK);
     const bool full = (pot->D == pot->DP);
-    static const bool use_v1 = (getenv("PBBI_DENSE_V1") != nullptr);  // A/B switches for profiling
-    static const bool use_v2 = (getenv("PBBI_DENSE_V2") != nullptr);
-    if (method == PBBI_LEAPFROG && !use_v1 && !use_v2) {
+    static const bool use_v1 = (getenv("PBBI_DENSE_V1") != nullptr);  // A/B switch for profiling
+    if (method == PBBI_LEAPFROG && prm.L >= 1 && !use_v1) {
         const int64_t tiles2 = (N + CHAINS_PER_WG2 - 1) / CHAINS_PER_WG2;
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
-#define LAUNCH3(NT_, F_)                                                                 \
-    {                                                                                    \
-        if (int rc = set_lds(k_dense_leapfrog2<NT_, F_>, lds)) return rc;                \
-        hipLaunchKernelGGL((k_dense_leapfrog2<NT_, F_>), grid2, block2, lds, stream, prm); \
+        const bool zmean = pot->zero_mean;
+#define LAUNCH3(NT_, F_, M_, Z_)                                                           \
+    {                                                                                      \
+        if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_>, lds)) return rc;                \
+        hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_>), grid2, block2, lds, stream, prm); \
     }
-#define CASE3(NT_)                   \
-    if (pot->DP == 16 * NT_) {       \
-        if (full) LAUNCH3(NT_, true) \
-        else LAUNCH3(NT_, false)     \
+#define CASE3F(NT_, F_)                                   \
+    {                                                     \
+        if (prm.mode == 0) {                              \
+            if (zmean) LAUNCH3(NT_, F_, 0, true)          \
+            else LAUNCH3(NT_, F_, 0, false)               \
+        } else {                                          \
+            if (zmean) LAUNCH3(NT_, F_, 1, true)          \
+            else LAUNCH3(NT_, F_, 1, false)               \
+        }                                                 \
+    }
+#define CASE3(NT_)                    \
+    if (pot->DP == 16 * NT_) {        \
+        if (full) CASE3F(NT_, true)   \
+        else CASE3F(NT_, false)       \
     }
         CASE3(2) CASE3(4) CASE3(8)
 #undef CASE3
+#undef CASE3F
 #undef LAUNCH3
-        PBBI_HIP(hipGetLastError());
-        return PBBI_OK;
-    }
-    if (method == PBBI_LEAPFROG && !use_v1) {
-#define LAUNCH2(NT_, F_)                                                              \
-    {                                                                                 \
-        if (int rc = set_lds(k_dense_leapfrog<NT_, F_>, lds)) return rc;              \
-        hipLaunchKernelGGL((k_dense_leapfrog<NT_, F_>), grid, block, lds, stream, prm); \
-    }
-#define CASE2(NT_)                   \
-    if (pot->DP == 16 * NT_) {       \
-        if (full) LAUNCH2(NT_, true) \
-        else LAUNCH2(NT_, false)     \
-    }
-        CASE2(2) CASE2(4) CASE2(8)
-#undef CASE2
-#undef LAUNCH2
         PBBI_HIP(hipGetLastError());
         return PBBI_OK;
     }
@@ -1146,7 +849,11 @@ int dense_build_fragments(pbbi_potential* pot, const double* P, const double* me
                 const double val = (i < D && k < D) ? P[(size_t)i * D + k] : 0.0;
                 frag[(((size_t)s * (NT / 2) + t / 2) * 64 + l) * 2 + (t & 1)] = val;
             }
-    for (int d = 0; d < D; ++d) mu[d] = mean ? mean[d] : 0.0;
+    pot->zero_mean = true;
+    for (int d = 0; d < D; ++d) {
+        mu[d] = mean ? mean[d] : 0.0;
+        if (mu[d] != 0.0) pot->zero_mean = false;
+    }
     PBBI_HIP(hipMalloc(&pot->d_frag, frag.size() * sizeof(double)));
     PBBI_HIP(hipMalloc(&pot->d_mean_pad, mu.size() * sizeof(double)));
     PBBI_HIP(hipMemcpy(pot->d_frag, frag.data(), frag.size() * sizeof(double), hipMemcpyHostToDevice));

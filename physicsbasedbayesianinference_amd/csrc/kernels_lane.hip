@@ -11,6 +11,7 @@
 //   StormerVerlet.integrate   src/integrator.py:142-163
 //   H = 0.5*dot(p,p)/m + U    src/HMC.py:100-102,109-115
 //   accept/reject + stores    src/HMC.py:164-179
+#include "pbbi_buf.h"
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
 
@@ -159,6 +160,28 @@ __device__ __forceinline__ T hamiltonian(const Pot& pot, const T (&q)[DMAX], con
     return T(0.5) * pp / m + pot.U(q);
 }
 
+// momentum draw of one chain: one Philox block per four dims (RNG contract, include/pbbi.h)
+template <typename T, int DMAX>
+__device__ __forceinline__ void draw_momentum(T (&p)[DMAX], int D, uint64_t seed, uint64_t iter,
+                                              uint64_t chain, double pstd) {
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) p[d] = T(0);
+#pragma unroll
+    for (int G = 0; G < (DMAX + 15) / 16; ++G)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * G + r < DMAX) {
+                float z[4];
+                rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), z);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int d = 16 * G + r + 4 * sl;
+                    if (d < DMAX) p[d] = (d < D) ? (T)((double)z[sl] * pstd) : T(0);
+                }
+            }
+        }
+}
+
 // -------------------------------------------------------------------- kernels
 template <typename T>
 struct HmcPrm {
@@ -179,29 +202,34 @@ struct HmcPrm {
 
 template <typename T, typename Pot, int DMAX, int METHOD>
 __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
-    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * BLOCK;  // block-uniform base chain
+    const int64_t n = n0 + threadIdx.x;
     if (n >= prm.N) return;
     const int D = prm.D;
     const bool unit = (prm.mass == nullptr);
     const T m = unit ? T(1) : prm.mass[n];
     const uint64_t chain = prm.chain0 + (uint64_t)n;
-    T pstd = T(1);
-    if (prm.rng) pstd = (T)sqrt((double)m * prm.kT);  // src/ensemble.py:88
+    // buffer addressing (pbbi_buf.h): one per-lane byte offset for every row of every array
+    const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
+    const uint32_t rin = (uint32_t)prm.ldn_in * (uint32_t)sizeof(T);
+    const uint32_t rout = (uint32_t)prm.ldn_out * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0);
+    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0);
+    const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
 
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? prm.q_in[(int64_t)d * prm.ldn_in + n] : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * rin) : T(0);
     T u;
     if (prm.rng) {
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d)
-            p[d] = (d < D) ? (T)(rng_normal(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, d)) * pstd
-                           : T(0);
+        draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
         u = (T)rng_uniform(prm.seed, prm.iter, chain);
     } else {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            p[d] = (d < D) ? prm.p_in[(int64_t)d * prm.ldn_in + n] : T(0);
+            p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * rin) : T(0);
         u = prm.u_in[n];
     }
     const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
@@ -213,30 +241,27 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     if (reject) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (d < D) q[d] = prm.q_in[(int64_t)d * prm.ldn_in + n];  // :175
+            if (d < D) q[d] = buf_load<T>(bq, voff, (uint32_t)d * rin);  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d) p[d] = q[d];
             } else if (prm.rng) {
-#pragma unroll
-                for (int d = 0; d < DMAX; ++d)
-                    if (d < D)
-                        p[d] = (T)(rng_normal(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, d)) * pstd;
+                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
             } else {
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d)
-                    if (d < D) p[d] = prm.p_in[(int64_t)d * prm.ldn_in + n];
+                    if (d < D) p[d] = buf_load<T>(bp, voff, (uint32_t)d * rin);
             }
         }
     }
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        if (d < D) prm.q_out[(int64_t)d * prm.ldn_out + n] = q[d];
+        if (d < D) buf_store(bqo, voff, (uint32_t)d * rout, q[d]);
     if (prm.p_out) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (d < D) prm.p_out[(int64_t)d * prm.ldn_out + n] = p[d];
+            if (d < D) buf_store(bpo, voff, (uint32_t)d * rout, p[d]);
     }
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
@@ -255,24 +280,30 @@ struct IntPrm {
 
 template <typename T, typename Pot, int DMAX, int METHOD>
 __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot) {
-    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t n = n0 + threadIdx.x;
     if (n >= prm.N) return;
     const int D = prm.D;
     const bool unit = (prm.mass == nullptr);
     const T m = unit ? T(1) : prm.mass[n];
+    const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
+    const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
+    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
+    const __amdgpu_buffer_rsrc_t bv = buf_make(prm.v_out + n0);
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
-        q[d] = (d < D) ? prm.q[(int64_t)d * prm.ldn + n] : T(0);
-        p[d] = (d < D) ? prm.p[(int64_t)d * prm.ldn + n] : T(0);
+        q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
+        p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
     }
     integrate_chain<T, Pot, DMAX, METHOD>(pot, q, p, v, m, unit, prm.h, prm.L);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
         if (d < D) {
-            prm.q[(int64_t)d * prm.ldn + n] = q[d];
-            prm.p[(int64_t)d * prm.ldn + n] = p[d];
-            if (prm.v_out) prm.v_out[(int64_t)d * prm.ldn + n] = v[d];
+            buf_store(bq, voff, (uint32_t)d * row, q[d]);
+            buf_store(bp, voff, (uint32_t)d * row, p[d]);
+            if (prm.v_out) buf_store(bv, voff, (uint32_t)d * row, v[d]);
         }
 }
 
@@ -290,26 +321,32 @@ struct EvalPrm {
 
 template <typename T, typename Pot, int DMAX>
 __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
-    const int64_t n = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t n = n0 + threadIdx.x;
     if (n >= prm.N) return;
     const int D = prm.D;
+    const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
+    const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
     T q[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? prm.q[(int64_t)d * prm.ldn + n] : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
     if (prm.mode == 0) {
         if (prm.U_out) prm.U_out[n] = pot.U(q);
         if (prm.grad_out) {
+            const __amdgpu_buffer_rsrc_t bg = buf_make(prm.grad_out + n0);
             T g[DMAX];
             pot.grad(q, g);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                if (d < D) prm.grad_out[(int64_t)d * prm.ldn + n] = g[d];
+                if (d < D) buf_store(bg, voff, (uint32_t)d * row, g[d]);
         }
         return;
     }
+    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
     T p[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) p[d] = (d < D) ? prm.p[(int64_t)d * prm.ldn + n] : T(0);
+    for (int d = 0; d < DMAX; ++d) p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
     const T m = prm.mass ? prm.mass[n] : T(1);
     const T H = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
     if (prm.mode == 1) {
@@ -438,6 +475,14 @@ int launch_eval(const EvalArgs& a, int mode) {
     return PBBI_OK;
 }
 
+int check_ld(const pbbi_potential* pot, int64_t ld) {
+    if ((int64_t)pot->D * ld >= ((int64_t)1 << 28))
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
+                         "chain-per-lane kernels address rows with 32-bit byte offsets: D * leading "
+                         "stride must be < 2^28 elements; shard the ensemble");
+    return PBBI_OK;
+}
+
 int check(const pbbi_potential* pot) {
     if (pick_dmax(pot->D) == 0)
         return pbbi_fail(PBBI_ERR_UNSUPPORTED,
@@ -450,21 +495,25 @@ int check(const pbbi_potential* pot) {
 
 int lane_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
     return a.pot->dtype == PBBI_F64 ? launch_hmc<double>(a) : launch_hmc<float>(a);
 }
 int lane_integrate(const IntegrateArgs& a) {
     if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     return a.pot->dtype == PBBI_F64 ? launch_integrate<double>(a) : launch_integrate<float>(a);
 }
 int lane_eval(const EvalArgs& a) {
     if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, 0) : launch_eval<float>(a, 0);
 }
 int lane_energy(const EvalArgs& a) {
     if (int rc = check(a.pot)) return rc;
+    if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     const int mode = a.ratio_finish ? 2 : 1;
     return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, mode) : launch_eval<float>(a, mode);

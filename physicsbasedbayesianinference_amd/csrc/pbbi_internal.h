@@ -21,6 +21,7 @@ struct pbbi_potential {
     int DP;        // D padded to a multiple of 16 (0 = path not available)
     void* d_frag;  // DP*DP elements: precision in MFMA A-fragment order
     void* d_mean_pad;  // DP elements, zero padded
+    bool zero_mean;    // every mean entry is exactly 0 (x = q, no subtraction needed)
 };
 
 // ---- error plumbing ---------------------------------------------------------

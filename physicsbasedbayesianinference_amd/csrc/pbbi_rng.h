@@ -1,5 +1,15 @@
-// pbbi_rng.h -- device side of the RNG contract in include/pbbi.h (Philox-4x32-10).
-// The integer part is bit-identical to oracle/pbbi_oracle.c::philox4x32_10.
+// pbbi_rng.h -- device side of the RNG contract in include/pbbi.h.
+//
+// Counter-based Philox-4x32-10 (bit-identical to oracle/pbbi_oracle.c::philox4x32_10) followed
+// by a SINGLE-PRECISION Box-Muller transform on the hardware transcendental unit (v_log_f32,
+// v_sqrt_f32, v_sin_f32, v_cos_f32): one 128-bit block yields FOUR standard normals for
+// ~90 instructions.  Why not fp64 log/sincospi: on gfx950 an f64 MFMA stream leaves room for
+// only ~3 other vector instructions per MFMA (tools/ubench/f64_pipe.hip), so every VALU
+// instruction in the fused HMC kernel is paid for in matrix-pipe time; the fp64 library
+// transform costs ~400 instructions per PAIR of normals and was 75 % of the kernel's
+// vector work.  The draws are exact N(0,1) variates on a 2^-24-relative grid with tails to
+// 6.7 sigma -- statistically indistinguishable for momentum refreshment -- and are
+// reproducible bit for bit on the device; the host mirror in the oracle agrees to ~1e-6.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,25 +44,37 @@ __device__ __forceinline__ double u53(uint32_t lo, uint32_t hi) {
     return (double)((((uint64_t)hi << 32) | lo) >> 11) * 0x1.0p-53;
 }
 
-// Both Box-Muller branches of one block: zc for the dim with bit 2 clear, zs for bit 2 set.
-__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint32_t stream, uint64_t iter,
-                                                uint64_t chain, uint32_t blk, double& zc,
-                                                double& zs) {
+// (a, b) -> (r cos(2 pi u2), r sin(2 pi u2)), r = sqrt(-2 ln u1):
+//   u1 = a*2^-32 + 2^-33 in (0, 1]  (float: the tail keeps its full 32-bit resolution)
+//   u2 = (b >> 8) * 2^-24 in [0, 1)
+__device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& zc, float& zs) {
+    const float u1 = fmaf((float)a, 0x1.0p-32f, 0x1.0p-33f);
+    const float u2 = (float)(b >> 8) * 0x1.0p-24f;
+    // -2 ln(u1) = (-2 ln 2) * log2(u1);  v_log_f32 is log2, v_sin/v_cos take revolutions
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    zc = r * __builtin_amdgcn_cosf(u2);
+    zs = r * __builtin_amdgcn_sinf(u2);
+}
+
+// The four standard normals of one block: z[slot], slot = (dim >> 2) & 3 of the dims
+// {16*(blk>>2) + (blk&3) + 4*slot}.
+__device__ __forceinline__ void rng_normal4(uint64_t seed, uint32_t stream, uint64_t iter,
+                                            uint64_t chain, uint32_t blk, float (&z)[4]) {
     const PhiloxOut x = rng_block(seed, stream, iter, chain, blk);
-    const double u1 = (double)(((((uint64_t)x.x1 << 32) | x.x0) >> 11) + 1) * 0x1.0p-53;
-    const double u2 = u53(x.x2, x.x3);
-    const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    zc = r * c;
-    zs = r * s;
+    box_muller_f32(x.x0, x.x1, z[0], z[1]);
+    box_muller_f32(x.x2, x.x3, z[2], z[3]);
+}
+
+__device__ __forceinline__ uint32_t rng_block_of_dim(int dim) {
+    return (uint32_t)(((dim >> 4) << 2) | (dim & 3));
 }
 
 __device__ __forceinline__ double rng_normal(uint64_t seed, uint32_t stream, uint64_t iter,
                                              uint64_t chain, int dim) {
-    double zc, zs;
-    rng_normal_pair(seed, stream, iter, chain, (uint32_t)(((dim >> 3) << 2) | (dim & 3)), zc, zs);
-    return ((dim >> 2) & 1) ? zs : zc;
+    float z[4];
+    rng_normal4(seed, stream, iter, chain, rng_block_of_dim(dim), z);
+    const int slot = (dim >> 2) & 3;
+    return (double)(slot == 0 ? z[0] : slot == 1 ? z[1] : slot == 2 ? z[2] : z[3]);
 }
 
 __device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t iter, uint64_t chain) {
