@@ -52,18 +52,36 @@ def bytes_per_step_chain(d, L, w=8):
     return (4.0 * d * w + w + 1) / L
 
 
-def cpu_baseline(Pm, L, seconds_target=15.0):
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc.json, produced by tools/run_profiles.sh + tools/summarize_profiles.py with
+    the FETCH_SIZE calibration described there).  None if no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f)).get("derived", {})
+            if "k_dense_hmc_hbm_bytes_per_launch" in d:
+                return d["k_dense_hmc_hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
+def cpu_baseline(Pm, L, seconds_target=4.0):
     """The oracle (CPU restatement of the reference loop; 'port'), all host threads, on a
     bounded sample of the same workload: same D, L, potential; fewer chains."""
     from oracle import oracle as orc
     pot = orc.pot_gauss_dense(np.zeros(D), Pm)
-    threads = orc.max_threads()
+    # the box's CPU share for one GPU is 16 cores (affinity may show the whole host)
+    threads = max(1, min(16, len(os.sched_getaffinity(0)), orc.max_threads()))
+    orc.set_threads(threads)
     n_probe = 64 * threads
     q = orc.philox_normal(1, orc.STREAM_POSITION, 0, 0, D, n_probe)
     t0 = time.perf_counter()
     orc.hmc_run_philox(pot, "Leapfrog", q, None, STEP, L, 1, seed=1, want_momenta=True)
     t_probe = time.perf_counter() - t0
-    n = int(min(N_PER_GPU, max(n_probe, n_probe * seconds_target / max(t_probe, 1e-3))))
+    n = int(min(4 * N_PER_GPU, max(n_probe, n_probe * seconds_target / max(t_probe, 1e-3))))
     n -= n % threads
     q = orc.philox_normal(1, orc.STREAM_POSITION, 0, 0, D, n)
     t0 = time.perf_counter()
@@ -72,14 +90,15 @@ def cpu_baseline(Pm, L, seconds_target=15.0):
     return {"value": n * L / dt, "unit": "leapfrog-steps*chains/s", "cores": threads,
             "kind": "port",
             "sample": f"oracle/pbbi_oracle.c hmc_run_philox, 1 HMC iteration, D={D}, "
-                      f"{n} chains, L={L}, OpenMP over chains, {dt:.1f} s wall"}
+                      f"{n} chains, L={L}, OpenMP over chains on {threads} threads, "
+                      f"{dt:.1f} s wall = {dt * threads:.0f} core-seconds"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chains", type=int, default=N_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -169,6 +188,7 @@ def main():
         kernel_s = dev_ms * 1e-3 / K  # average launch duration from HIP events on the launch stream
         flops_launch = flops_per_step_chain(D, L) * L * N
         bytes_launch = bytes_per_step_chain(D, L) * L * N
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "leapfrog-steps*chains/sec (node); d=128 Gaussian, ensemble=65536",
             "value": value,
@@ -188,10 +208,12 @@ def main():
                        "stepSize": STEP, "parallelism": f"ensemble-sharded x{world}",
                        "accept_rate": accept},
             "roofline": {
-                "bound": "mfma", "kernel": "k_dense_traj<8, LEAPFROG, full>",
+                "bound": "mfma", "kernel": "k_dense_hmc<8, full, hmc, zero-mean>",
                 "achieved": flops_launch / kernel_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flops_launch / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_flops_per_launch": flops_launch,
+                "algorithmic_bytes_per_launch": bytes_launch,
                 "launch_ms": kernel_s * 1e3,
                 "hbm_algorithmic_GBs": bytes_launch / kernel_s / 1e9,
                 "hbm_frac_of_8TBs": bytes_launch / kernel_s / 1e9 / HBM_PEAK_GBS,

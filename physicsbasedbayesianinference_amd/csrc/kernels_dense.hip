@@ -4,28 +4,35 @@
 // (x = q - mu): a (DP x DP)·(DP x 16) product per 16-chain tile, done on the matrix cores
 // with v_mfma_f64_16x16x4_f64.  Design (MI355X-first, not a translation of anything):
 //
-//   * One wave owns a tile of 16 chains for the WHOLE trajectory.  Its q, v, a and the
-//     mat-vec accumulator live in VGPR/AGPRs: lane (g = lane>>4, c = lane&15) holds, for
-//     chain c, the dims {4s+g : s = 0..DP/4-1}.  That is simultaneously
+//   * One wave owns a tile of 16 chains for the WHOLE trajectory; its state and the mat-vec
+//     accumulator live in registers: lane (g = lane>>4, c = lane&15) holds, for chain c, the
+//     dims {4s+g : s = 0..DP/4-1}.  That is simultaneously
 //        - the B-operand layout of K-step s      (B[k = lane>>4][n = lane&15]), and
 //        - the C/D layout of row tile t, reg r   (row = (lane>>4) + 4r -> dim 16t+4r+g, s = 4t+r),
 //     so the MFMA output lands exactly where the next step's operand lives: the
 //     leapfrog update is lane-local, no shuffles, no LDS round trip for state.
-//   * P (128 KiB at D=128) is staged ONCE per workgroup into LDS, pre-swizzled on the host
+//   * P (128 KiB at D=128) is staged once per workgroup into LDS, pre-swizzled on the host
 //     into A-fragment order [s][t/2][lane][2] so that each ds_read_b128 is lane-linear
-//     (conflict-free) and feeds two MFMAs.  mu sits next to it (1 KiB).
-//   * Workgroups are persistent: grid = min(#tiles, #CUs), grid-stride over 64-chain
-//     tiles; 129 KiB of LDS pins one workgroup (4 waves, one per SIMD) per CU, and a
-//     wave may use the full 512-register budget.
+//     (conflict-free) and feeds two MFMAs.  mu sits next to it (1 KiB).  129 KiB of LDS
+//     pins one workgroup per CU.  P is shared through L2 only (every workgroup reads the
+//     same 128 KiB), chains share nothing: there is no inter-tile reuse for an XCD-aware
+//     block mapping to exploit, so blockIdx maps to tiles directly.
 //   * U(q) = 0.5 x.(P x) reuses the gradient mat-vec (first and last evaluation of the
 //     trajectory), so an HMC iteration costs exactly L+1 mat-vecs.
-//   * Kinetic/potential sums: 32 lane-local terms, then a 2-step xor butterfly over the
-//     4 lanes that share a chain (every lane ends with identical bits -> uniform decision).
+//   * Kinetic/potential sums: lane-local terms, then a 2-step xor butterfly over the 4 lanes
+//     that share a chain (every lane ends with identical bits -> uniform decision).
 //
-// Arithmetic per element follows the reference's operation order (src/integrator.py:105-120,
-// :142-163; src/HMC.py:100-102,115,164-179); only the summation ORDER inside dot products
-// differs from the oracle (MFMA k-ordered fma chain, lane-group butterfly), so parity with
-// the oracle is to fp64 tolerance with equal reject masks, not bitwise.
+// Two kernels share these pieces:
+//   k_dense_hmc   production path, Leapfrog with L >= 1: two waves per SIMD, kick-drift-kick
+//                 state, row passes (see the comment above it; 76 % of the fp64 MFMA peak).
+//   k_dense_traj  general path: Stormer-Verlet, L = 0, and the reference's velocity-Verlet
+//                 operation order for Leapfrog (A/B switch PBBI_DENSE_V1): one wave per SIMD,
+//                 512-register budget, matrix pipe ~50 % busy.
+//
+// Only the summation ORDER inside dot products (MFMA k-ordered fma chain, lane-group
+// butterfly) and, in k_dense_hmc, the algebraically equivalent kick-drift-kick update differ
+// from the oracle, so parity is to fp64 tolerance with equal reject masks, not bitwise
+// (src/integrator.py:105-120, :142-163; src/HMC.py:100-102,115,164-179).
 #include <cstdlib>
 #include <vector>
 
@@ -48,6 +55,18 @@ constexpr int CHAINS_PER_WG = 64;
 // the run time of such a build; read the SHARES.
 static unsigned long long* g_stamp_buf = nullptr;
 extern "C" void pbbi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+// PBBI_STAMPS=1: every phase (s_memtime, shader cycles).  PBBI_STAMPS=2: only entry/exit, taken
+// with s_memrealtime (100 MHz, one clock for the whole chip) for the workgroup timeline.
+#if PBBI_STAMPS == 2
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        if (((i) == 0 || (i) == 41) && prm.stamps && lane == 0) {                     \
+            unsigned long long t_;                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            prm.stamps[((size_t)blockIdx.x * 8 + wave) * 64 + (i)] = t_;              \
+        }                                                                             \
+    } while (0)
+#else
 #define STAMP(i)                                                                      \
     do {                                                                              \
         if (prm.stamps && lane == 0) {                                                \
@@ -58,6 +77,7 @@ extern "C" void pbbi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned l
             __builtin_amdgcn_sched_barrier(0);                                        \
         }                                                                             \
     } while (0)
+#endif
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -396,7 +416,8 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
 //      v = p*(1/m), a = -(g*(1/m)) (exact for the reference's default unit masses).
 //   2. The 128 output rows of each mat-vec are produced in two PASSES of 64 rows, so the live
 //      accumulator is 32 registers, not 64; same MFMA count, x_s is simply formed twice.
-//   3. One 128-chain tile per workgroup, no persistent loop, no run-time branches around the
+//   3. One 128-chain tile per workgroup, no persistent loop (a grid-stride variant measured the
+//      same throughput and spills twice as much), no run-time branches around the
 //      register arrays, buffer (SRSRC) addressing: in a loop hipcc hoists every loop-invariant
 //      (~60 fp64 polynomial constants of log/sincospi/exp, all row offsets) and keeps them
 //      live for the whole kernel (~140 VGPRs); branches around array updates double the

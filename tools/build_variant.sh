@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build a variant of libpbbi with extra flags on kernels_dense.hip only:
+#   tools/build_variant.sh <name> <flags...>   ->  build/<name>/libpbbi.so   (use with PBBI_LIB=)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+C=physicsbasedbayesianinference_amd/csrc
+make -C $C -j3 >/dev/null
+mkdir -p build/$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" \
+    -c $C/kernels_dense.hip -o build/$name/kernels_dense.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/$name/libpbbi.so \
+    $C/pbbi_api.o $C/kernels_lane.o build/$name/kernels_dense.o
+echo build/$name/libpbbi.so
