@@ -11,6 +11,8 @@
 //   StormerVerlet.integrate   src/integrator.py:142-163
 //   H = 0.5*dot(p,p)/m + U    src/HMC.py:100-102,109-115
 //   accept/reject + stores    src/HMC.py:164-179
+#include <type_traits>
+
 #include "pbbi_buf.h"
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
@@ -20,7 +22,7 @@ namespace {
 constexpr int BLOCK = 256;
 
 // ------------------------------------------------------------------ potentials
-template <typename T, int DMAX>
+template <typename T, int DMAX, bool FULL>
 struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
     const T* __restrict__ mean;
     const T* __restrict__ prec;
@@ -32,11 +34,11 @@ struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
         if (harmonic) {
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                if (d < D) acc += prec[d] * (q[d] * q[d]);
+                if (FULL || d < D) acc += prec[d] * (q[d] * q[d]);
         } else {
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                if (d < D) {
+                if (FULL || d < D) {
                     const T x = q[d] - mean[d];
                     acc += (prec[d] * x) * x;
                 }
@@ -45,11 +47,17 @@ struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
     }
     __device__ __forceinline__ void grad(const T (&q)[DMAX], T (&g)[DMAX]) const {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) g[d] = (d < D) ? prec[d] * (q[d] - mean[d]) : T(0);
+        for (int d = 0; d < DMAX; ++d) g[d] = (FULL || d < D) ? prec[d] * (q[d] - mean[d]) : T(0);
+    }
+    // visit(d, g_d) for d = 0..DMAX-1 in order, one element at a time (no g[] array live)
+    template <typename F>
+    __device__ __forceinline__ void grad_each(const T (&q)[DMAX], F&& visit) const {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) visit(d, (FULL || d < D) ? prec[d] * (q[d] - mean[d]) : T(0));
     }
 };
 
-template <typename T, int DMAX>
+template <typename T, int DMAX, bool FULL>
 struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t = q_{i+1} - q_i^2
     T a, b, inv_s, cst;
     int D;
@@ -57,13 +65,13 @@ struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t = q_{i+1}
         T s1 = T(0), s2 = T(0);
 #pragma unroll
         for (int i = 0; i + 1 < DMAX; ++i)
-            if (i + 1 < D) {
+            if (FULL || i + 1 < D) {
                 const T t = q[i + 1] - q[i] * q[i];
                 s1 += (b * t) * t;
             }
 #pragma unroll
         for (int i = 0; i + 1 < DMAX; ++i)
-            if (i + 1 < D) {
+            if (FULL || i + 1 < D) {
                 const T r = a - q[i];
                 s2 += r * r;
             }
@@ -74,21 +82,37 @@ struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t = q_{i+1}
         for (int d = 0; d < DMAX; ++d) g[d] = T(0);
 #pragma unroll
         for (int i = 0; i + 1 < DMAX; ++i)
-            if (i + 1 < D) {
+            if (FULL || i + 1 < D) {
                 const T t = q[i + 1] - q[i] * q[i];
                 g[i] += (((T(-4) * b) * q[i]) * t - T(2) * (a - q[i])) * inv_s;
                 g[i + 1] += ((T(2) * b) * t) * inv_s;
             }
     }
+    // Same values as grad(), element by element: g_i = (0 + second_{i-1}) + first_i, where
+    // first_i = ((-4b q_i) t_i - 2(a - q_i))/s and second_i = (2b t_i)/s exist for i < D-1.
+    template <typename F>
+    __device__ __forceinline__ void grad_each(const T (&q)[DMAX], F&& visit) const {
+        T carry = T(0);  // second_{i-1}
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) {
+            T gi = carry;
+            carry = T(0);
+            if (i + 1 < DMAX && (FULL || i + 1 < D)) {
+                const T t = q[i + 1] - q[i] * q[i];
+                gi += (((T(-4) * b) * q[i]) * t - T(2) * (a - q[i])) * inv_s;
+                carry = ((T(2) * b) * t) * inv_s;
+            }
+            visit(i, (FULL || i < D) ? gi : T(0));
+        }
+    }
 };
 
 // ---------------------------------------------------------------- integrators
-template <typename T, typename Pot, int DMAX>
-__device__ __forceinline__ void accel(const Pot& pot, const T (&q)[DMAX], T m, bool unit,
-                                      T (&a)[DMAX]) {
+template <typename T, typename Pot, int DMAX, bool UNIT>
+__device__ __forceinline__ void accel(const Pot& pot, const T (&q)[DMAX], T m, T (&a)[DMAX]) {
     T g[DMAX];
     pot.grad(q, g);
-    if (unit) {
+    if constexpr (UNIT) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) a[d] = -g[d];
     } else {
@@ -97,13 +121,14 @@ __device__ __forceinline__ void accel(const Pot& pot, const T (&q)[DMAX], T m, b
     }
 }
 
-template <typename T, typename Pot, int DMAX, int METHOD>
+// UNIT: every mass is exactly 1 (mass == NULL): v = p, a = -g, p = v, no fp64 divisions.
+template <typename T, typename Pot, int DMAX, int METHOD, bool UNIT>
 __device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T (&p)[DMAX],
-                                                T (&v)[DMAX], T m, bool unit, T h, int L) {
+                                                T (&v)[DMAX], T m, T h, int L) {
     const T h2 = h * h;
     const T half = T(0.5);
     T a[DMAX];
-    if (unit) {
+    if constexpr (UNIT) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) v[d] = p[d];
     } else {
@@ -111,27 +136,27 @@ __device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T 
         for (int d = 0; d < DMAX; ++d) v[d] = p[d] / m;
     }
     if constexpr (METHOD == PBBI_LEAPFROG) {
-        accel<T, Pot, DMAX>(pot, q, m, unit, a);
+        // a = getAccel(q) (:108); the gradient is consumed element by element so that only
+        // q, v, a are live (3*DMAX registers instead of 5*DMAX with separate g[] / a'[] arrays)
+        pot.grad_each(q, [&](int d, T g) { a[d] = UNIT ? -g : -g / m; });
         for (int j = 0; j < L; ++j) {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + (half * a[d]) * h2);
-            T an[DMAX];
-            accel<T, Pot, DMAX>(pot, q, m, unit, an);
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) {
-                v[d] += (half * (a[d] + an[d])) * h;
-                a[d] = an[d];
-            }
+            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + (half * a[d]) * h2);  // :112-115
+            pot.grad_each(q, [&](int d, T g) {                                       // :116-118
+                const T an = UNIT ? -g : -g / m;
+                v[d] += (half * (a[d] + an)) * h;
+                a[d] = an;
+            });
         }
     } else {
         T qpast[DMAX];
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) qpast[d] = q[d];
-        accel<T, Pot, DMAX>(pot, q, m, unit, a);
+        accel<T, Pot, DMAX, UNIT>(pot, q, m, a);
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) q[d] = (q[d] + v[d] * h) + (half * a[d]) * h2;
         for (int j = 0; j < L; ++j) {
-            accel<T, Pot, DMAX>(pot, q, m, unit, a);
+            accel<T, Pot, DMAX, UNIT>(pot, q, m, a);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
                 const T cur = q[d];
@@ -142,7 +167,7 @@ __device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T 
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) v[d] = (q[d] - qpast[d]) / h;
     }
-    if (unit) {
+    if constexpr (UNIT) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) p[d] = v[d];
     } else {
@@ -176,7 +201,7 @@ __device__ __forceinline__ void draw_momentum(T (&p)[DMAX], int D, uint64_t seed
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     const int d = 16 * G + r + 4 * sl;
-                    if (d < DMAX) p[d] = (d < D) ? (T)((double)z[sl] * pstd) : T(0);
+                    if (d < DMAX) p[d] = (d < D) ? (T)((double)z[sl] * pstd) : T(0);  // D uniform
                 }
             }
         }
@@ -200,14 +225,13 @@ struct HmcPrm {
     double kT;
 };
 
-template <typename T, typename Pot, int DMAX, int METHOD>
+template <typename T, typename Pot, int DMAX, int METHOD, bool FULL, bool UNIT>
 __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const int64_t n0 = (int64_t)blockIdx.x * BLOCK;  // block-uniform base chain
     const int64_t n = n0 + threadIdx.x;
     if (n >= prm.N) return;
     const int D = prm.D;
-    const bool unit = (prm.mass == nullptr);
-    const T m = unit ? T(1) : prm.mass[n];
+    const T m = UNIT ? T(1) : prm.mass[n];
     const uint64_t chain = prm.chain0 + (uint64_t)n;
     // buffer addressing (pbbi_buf.h): one per-lane byte offset for every row of every array
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
@@ -221,7 +245,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
 
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * rin) : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * rin) : T(0);
     T u;
     if (prm.rng) {
         draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
@@ -229,11 +253,11 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     } else {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * rin) : T(0);
+            p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * rin) : T(0);
         u = prm.u_in[n];
     }
     const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
-    integrate_chain<T, Pot, DMAX, METHOD>(pot, q, p, v, m, unit, prm.h, prm.L);
+    integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
     const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);  // p -> -p leaves dot(p,p) unchanged
     const T ratio = exp(oldH - newH);                        // src/HMC.py:115
     // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
@@ -241,7 +265,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     if (reject) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (d < D) q[d] = buf_load<T>(bq, voff, (uint32_t)d * rin);  // :175
+            if (FULL || d < D) q[d] = buf_load<T>(bq, voff, (uint32_t)d * rin);  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -251,17 +275,17 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
             } else {
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d)
-                    if (d < D) p[d] = buf_load<T>(bp, voff, (uint32_t)d * rin);
+                    if (FULL || d < D) p[d] = buf_load<T>(bp, voff, (uint32_t)d * rin);
             }
         }
     }
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        if (d < D) buf_store(bqo, voff, (uint32_t)d * rout, q[d]);
+        if (FULL || d < D) buf_store(bqo, voff, (uint32_t)d * rout, q[d]);
     if (prm.p_out) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (d < D) buf_store(bpo, voff, (uint32_t)d * rout, p[d]);
+            if (FULL || d < D) buf_store(bpo, voff, (uint32_t)d * rout, p[d]);
     }
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
@@ -278,14 +302,13 @@ struct IntPrm {
     int L, D;
 };
 
-template <typename T, typename Pot, int DMAX, int METHOD>
+template <typename T, typename Pot, int DMAX, int METHOD, bool FULL, bool UNIT>
 __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot) {
     const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t n = n0 + threadIdx.x;
     if (n >= prm.N) return;
     const int D = prm.D;
-    const bool unit = (prm.mass == nullptr);
-    const T m = unit ? T(1) : prm.mass[n];
+    const T m = UNIT ? T(1) : prm.mass[n];
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
     const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
     const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
@@ -294,13 +317,13 @@ __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
-        q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
-        p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
+        q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
+        p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
     }
-    integrate_chain<T, Pot, DMAX, METHOD>(pot, q, p, v, m, unit, prm.h, prm.L);
+    integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        if (d < D) {
+        if (FULL || d < D) {
             buf_store(bq, voff, (uint32_t)d * row, q[d]);
             buf_store(bp, voff, (uint32_t)d * row, p[d]);
             if (prm.v_out) buf_store(bv, voff, (uint32_t)d * row, v[d]);
@@ -319,7 +342,7 @@ struct EvalPrm {
     int D, mode;  // mode 0: eval (U, grad); 1: energy H/w; 2: ratio finish U_out = exp(U_out - H)
 };
 
-template <typename T, typename Pot, int DMAX>
+template <typename T, typename Pot, int DMAX, bool FULL>
 __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
     const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t n = n0 + threadIdx.x;
@@ -330,7 +353,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
     const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
     T q[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
     if (prm.mode == 0) {
         if (prm.U_out) prm.U_out[n] = pot.U(q);
         if (prm.grad_out) {
@@ -339,14 +362,14 @@ __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
             pot.grad(q, g);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                if (d < D) buf_store(bg, voff, (uint32_t)d * row, g[d]);
+                if (FULL || d < D) buf_store(bg, voff, (uint32_t)d * row, g[d]);
         }
         return;
     }
     const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
     T p[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) p[d] = (d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
+    for (int d = 0; d < DMAX; ++d) p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
     const T m = prm.mass ? prm.mass[n] : T(1);
     const T H = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
     if (prm.mode == 1) {
@@ -364,19 +387,73 @@ int pick_dmax(int D) {
     return 0;
 }
 
-template <typename T, int DMAX>
-SeparablePot<T, DMAX> make_sep(const pbbi_potential* pot) {
-    return SeparablePot<T, DMAX>{(const T*)pot->d_mean, (const T*)pot->d_prec, (T)pot->cst, pot->D,
-                                 pot->kind == KIND_HARMONIC ? 1 : 0};
+template <typename T, int DMAX, bool FULL>
+SeparablePot<T, DMAX, FULL> make_sep(const pbbi_potential* pot) {
+    return SeparablePot<T, DMAX, FULL>{(const T*)pot->d_mean, (const T*)pot->d_prec, (T)pot->cst,
+                                       pot->D, pot->kind == KIND_HARMONIC ? 1 : 0};
 }
-template <typename T, int DMAX>
-RosenbrockPot<T, DMAX> make_ros(const pbbi_potential* pot) {
-    return RosenbrockPot<T, DMAX>{(T)pot->a, (T)pot->b, (T)(1.0 / pot->s), (T)pot->cst, pot->D};
+template <typename T, int DMAX, bool FULL>
+RosenbrockPot<T, DMAX, FULL> make_ros(const pbbi_potential* pot) {
+    return RosenbrockPot<T, DMAX, FULL>{(T)pot->a, (T)pot->b, (T)(1.0 / pot->s), (T)pot->cst, pot->D};
 }
 
 inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + BLOCK - 1) / BLOCK)); }
 
-#define FOR_EACH_DMAX(X) X(2) X(4) X(8) X(16) X(32) X(64)
+// run-time value -> compile-time template argument
+template <typename F>
+void with_dmax(int D, F&& f) {
+    switch (pick_dmax(D)) {
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    case 16: f(std::integral_constant<int, 16>{}); break;
+    case 32: f(std::integral_constant<int, 32>{}); break;
+    case 64: f(std::integral_constant<int, 64>{}); break;
+    default: break;
+    }
+}
+template <typename F>
+void with_bool(bool b, F&& f) {
+    if (b) f(std::true_type{});
+    else f(std::false_type{});
+}
+
+template <typename T, int DM, bool FULL, int METHOD, bool UNIT>
+void launch_hmc_k(const pbbi_potential* pot, const HmcPrm<T>& prm, dim3 grid, hipStream_t st) {
+    if (pot->kind == KIND_ROSENBROCK) {
+        auto f = make_ros<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_hmc<T, decltype(f), DM, METHOD, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                           st, prm, f);
+    } else {
+        auto f = make_sep<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_hmc<T, decltype(f), DM, METHOD, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                           st, prm, f);
+    }
+}
+
+template <typename T, int DM, bool FULL, int METHOD, bool UNIT>
+void launch_int_k(const pbbi_potential* pot, const IntPrm<T>& prm, dim3 grid, hipStream_t st) {
+    if (pot->kind == KIND_ROSENBROCK) {
+        auto f = make_ros<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_integrate<T, decltype(f), DM, METHOD, FULL, UNIT>), grid,
+                           dim3(BLOCK), 0, st, prm, f);
+    } else {
+        auto f = make_sep<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_integrate<T, decltype(f), DM, METHOD, FULL, UNIT>), grid,
+                           dim3(BLOCK), 0, st, prm, f);
+    }
+}
+
+template <typename T, int DM, bool FULL>
+void launch_eval_k(const pbbi_potential* pot, const EvalPrm<T>& prm, dim3 grid, hipStream_t st) {
+    if (pot->kind == KIND_ROSENBROCK) {
+        auto f = make_ros<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_eval<T, decltype(f), DM, FULL>), grid, dim3(BLOCK), 0, st, prm, f);
+    } else {
+        auto f = make_sep<T, DM, FULL>(pot);
+        hipLaunchKernelGGL((k_lane_eval<T, decltype(f), DM, FULL>), grid, dim3(BLOCK), 0, st, prm, f);
+    }
+}
 
 template <typename T>
 int launch_hmc(const IterArgs& a) {
@@ -385,31 +462,20 @@ int launch_hmc(const IterArgs& a) {
                   (T*)a.q_out, (T*)a.p_out, (T*)a.ratio_out, a.reject_out,
                   a.N, a.ldn_in, a.ldn_out, (T)a.h, a.L, pot->D, a.flags, a.rng,
                   a.seed, a.iter, a.chain0, a.kT};
-    const int dmax = pick_dmax(pot->D);
-    const bool ros = pot->kind == KIND_ROSENBROCK;
     const dim3 grid = grid_for(a.N);
-#define LAUNCH(DM)                                                                                 \
-    if (dmax == DM) {                                                                              \
-        if (ros) {                                                                                 \
-            auto f = make_ros<T, DM>(pot);                                                         \
-            if (a.method == PBBI_LEAPFROG)                                                         \
-                hipLaunchKernelGGL((k_lane_hmc<T, RosenbrockPot<T, DM>, DM, PBBI_LEAPFROG>), grid, \
-                                   dim3(BLOCK), 0, a.stream, prm, f);                              \
-            else                                                                                   \
-                hipLaunchKernelGGL((k_lane_hmc<T, RosenbrockPot<T, DM>, DM, PBBI_STORMER_VERLET>), \
-                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                        \
-        } else {                                                                                   \
-            auto f = make_sep<T, DM>(pot);                                                         \
-            if (a.method == PBBI_LEAPFROG)                                                         \
-                hipLaunchKernelGGL((k_lane_hmc<T, SeparablePot<T, DM>, DM, PBBI_LEAPFROG>), grid,  \
-                                   dim3(BLOCK), 0, a.stream, prm, f);                              \
-            else                                                                                   \
-                hipLaunchKernelGGL((k_lane_hmc<T, SeparablePot<T, DM>, DM, PBBI_STORMER_VERLET>),  \
-                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                        \
-        }                                                                                          \
-    }
-    FOR_EACH_DMAX(LAUNCH)
-#undef LAUNCH
+    with_dmax(pot->D, [&](auto dm) {
+        constexpr int DM = decltype(dm)::value;
+        with_bool(pot->D == DM, [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            with_bool(a.mass == nullptr, [&](auto unit) {
+                constexpr bool UNIT = decltype(unit)::value;
+                if (a.method == PBBI_LEAPFROG)
+                    launch_hmc_k<T, DM, FULL, PBBI_LEAPFROG, UNIT>(pot, prm, grid, a.stream);
+                else
+                    launch_hmc_k<T, DM, FULL, PBBI_STORMER_VERLET, UNIT>(pot, prm, grid, a.stream);
+            });
+        });
+    });
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
@@ -418,33 +484,20 @@ template <typename T>
 int launch_integrate(const IntegrateArgs& a) {
     const pbbi_potential* pot = a.pot;
     IntPrm<T> prm{(T*)a.q, (T*)a.p, (const T*)a.mass, (T*)a.v_out, a.N, a.ldn, (T)a.h, a.L, pot->D};
-    const int dmax = pick_dmax(pot->D);
-    const bool ros = pot->kind == KIND_ROSENBROCK;
     const dim3 grid = grid_for(a.N);
-#define LAUNCH(DM)                                                                               \
-    if (dmax == DM) {                                                                            \
-        if (ros) {                                                                               \
-            auto f = make_ros<T, DM>(pot);                                                       \
-            if (a.method == PBBI_LEAPFROG)                                                       \
-                hipLaunchKernelGGL((k_lane_integrate<T, RosenbrockPot<T, DM>, DM, PBBI_LEAPFROG>), \
-                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                      \
-            else                                                                                 \
-                hipLaunchKernelGGL(                                                              \
-                    (k_lane_integrate<T, RosenbrockPot<T, DM>, DM, PBBI_STORMER_VERLET>), grid,  \
-                    dim3(BLOCK), 0, a.stream, prm, f);                                           \
-        } else {                                                                                 \
-            auto f = make_sep<T, DM>(pot);                                                       \
-            if (a.method == PBBI_LEAPFROG)                                                       \
-                hipLaunchKernelGGL((k_lane_integrate<T, SeparablePot<T, DM>, DM, PBBI_LEAPFROG>), \
-                                   grid, dim3(BLOCK), 0, a.stream, prm, f);                      \
-            else                                                                                 \
-                hipLaunchKernelGGL(                                                              \
-                    (k_lane_integrate<T, SeparablePot<T, DM>, DM, PBBI_STORMER_VERLET>), grid,   \
-                    dim3(BLOCK), 0, a.stream, prm, f);                                           \
-        }                                                                                        \
-    }
-    FOR_EACH_DMAX(LAUNCH)
-#undef LAUNCH
+    with_dmax(pot->D, [&](auto dm) {
+        constexpr int DM = decltype(dm)::value;
+        with_bool(pot->D == DM, [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            with_bool(a.mass == nullptr, [&](auto unit) {
+                constexpr bool UNIT = decltype(unit)::value;
+                if (a.method == PBBI_LEAPFROG)
+                    launch_int_k<T, DM, FULL, PBBI_LEAPFROG, UNIT>(pot, prm, grid, a.stream);
+                else
+                    launch_int_k<T, DM, FULL, PBBI_STORMER_VERLET, UNIT>(pot, prm, grid, a.stream);
+            });
+        });
+    });
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
@@ -454,23 +507,13 @@ int launch_eval(const EvalArgs& a, int mode) {
     const pbbi_potential* pot = a.pot;
     EvalPrm<T> prm{(const T*)a.q, (const T*)a.p, (const T*)a.mass, (T*)a.U_out, (T*)a.grad_out,
                    (T*)a.w_out, a.N, a.ldn, pot->D, mode};
-    const int dmax = pick_dmax(pot->D);
-    const bool ros = pot->kind == KIND_ROSENBROCK;
     const dim3 grid = grid_for(a.N);
-#define LAUNCH(DM)                                                                              \
-    if (dmax == DM) {                                                                           \
-        if (ros) {                                                                              \
-            auto f = make_ros<T, DM>(pot);                                                      \
-            hipLaunchKernelGGL((k_lane_eval<T, RosenbrockPot<T, DM>, DM>), grid, dim3(BLOCK), 0, \
-                               a.stream, prm, f);                                               \
-        } else {                                                                                \
-            auto f = make_sep<T, DM>(pot);                                                      \
-            hipLaunchKernelGGL((k_lane_eval<T, SeparablePot<T, DM>, DM>), grid, dim3(BLOCK), 0,  \
-                               a.stream, prm, f);                                               \
-        }                                                                                       \
-    }
-    FOR_EACH_DMAX(LAUNCH)
-#undef LAUNCH
+    with_dmax(pot->D, [&](auto dm) {
+        constexpr int DM = decltype(dm)::value;
+        with_bool(pot->D == DM, [&](auto full) {
+            launch_eval_k<T, DM, decltype(full)::value>(pot, prm, grid, a.stream);
+        });
+    });
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
@@ -484,6 +527,8 @@ int check_ld(const pbbi_potential* pot, int64_t ld) {
 }
 
 int check(const pbbi_potential* pot) {
+    if (pot->dtype != PBBI_F64)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "chain-per-lane kernels are built for fp64 only");
     if (pick_dmax(pot->D) == 0)
         return pbbi_fail(PBBI_ERR_UNSUPPORTED,
                          "chain-per-lane kernels hold D <= 64 in registers; D = " +
@@ -497,24 +542,24 @@ int lane_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
-    return a.pot->dtype == PBBI_F64 ? launch_hmc<double>(a) : launch_hmc<float>(a);
+    return launch_hmc<double>(a);
 }
 int lane_integrate(const IntegrateArgs& a) {
     if (int rc = check(a.pot)) return rc;
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
-    return a.pot->dtype == PBBI_F64 ? launch_integrate<double>(a) : launch_integrate<float>(a);
+    return launch_integrate<double>(a);
 }
 int lane_eval(const EvalArgs& a) {
     if (int rc = check(a.pot)) return rc;
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
-    return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, 0) : launch_eval<float>(a, 0);
+    return launch_eval<double>(a, 0);
 }
 int lane_energy(const EvalArgs& a) {
     if (int rc = check(a.pot)) return rc;
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     const int mode = a.ratio_finish ? 2 : 1;
-    return a.pot->dtype == PBBI_F64 ? launch_eval<double>(a, mode) : launch_eval<float>(a, mode);
+    return launch_eval<double>(a, mode);
 }

@@ -429,3 +429,80 @@ def test_error_behaviour(P, lib):
     big = P.Harmonic(np.ones(65))  # chain-per-lane kernels hold D <= 64
     with pytest.raises(lib.PbbiError):
         big(np.zeros(65))
+
+
+# ------------------------------------------------------------------ sharded API / properties
+def test_get_samples_sharded_single_process_matches_class_api(P):
+    """distributed.get_samples_sharded without a process group == HMC.getSamples (philox and
+    numpy-stream modes), returned as (D, N, S) device views."""
+    from physicsbasedbayesianinference_amd.distributed import get_samples_sharded
+    D, N, S = 16, 200, 3
+    rs = np.random.RandomState(3)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    pot = P.GaussianDense(rs.standard_normal(D), precision=Pm, const=0.0)
+    for rng in ("philox", "numpy"):
+        np.random.seed(11)
+        s, m, hmc = get_samples_sharded(pot, D, N, 1.0, 0.1, S, 1 / kB, 1.0, rng=rng, seed=5)
+        np.random.seed(11)
+        ens = P.Ensemble(D, N)
+        s2, m2 = P.HMC(ens, 1.0, 0.1, None, potential=pot, rng=rng, seed=5, verbose=False).getSamples(
+            S, 1 / kB, 1.0)
+        assert tuple(s.shape) == (D, N, S)
+        assert np.array_equal(s.cpu().numpy(), s2) and np.array_equal(m.cpu().numpy(), m2)
+
+
+def test_sharding_invariance_on_device(P, lib):
+    """Philox mode: chains [0, N) in one call == two half-ensembles with chain0 offsets, bit for
+    bit (what makes the 8-GPU run reproduce the 1-GPU chains)."""
+    D, N, S = 128, 512, 3
+    rs = np.random.RandomState(4)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    pot = P.GaussianDense(None, precision=Pm, const=0.0)
+
+    def run(n, chain0):
+        hmc = P.HMC(P.Ensemble(D, n), 1.0, 0.1, None, potential=pot, rng="philox", seed=9,
+                    verbose=False)
+        return hmc.getSamples(S, 1 / kB, 1.0, chain0=chain0)[0]
+    full = run(N, 0)
+    lo, hi = run(N // 2, 0), run(N // 2, N // 2)
+    assert np.array_equal(full[:, :N // 2], lo) and np.array_equal(full[:, N // 2:], hi)
+
+
+def test_full_size_properties_c2(P, lib):
+    """Size-independent properties at BASELINE's full C2 size (D=128, 65 536 chains):
+    determinism, linearity of the Gaussian flow, time reversibility, energy error ~ h^2."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr
+    D, N, L, h = 128, 65536, 10, 0.1
+    A = np.random.RandomState(0).standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    pot = P.GaussianDense(None, precision=Pm, const=0.0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q0 = torch.randn((D, N), dtype=torch.float64, device="cuda", generator=g)
+    p0 = torch.randn((D, N), dtype=torch.float64, device="cuda", generator=g)
+
+    def leap(q, p, hh=h, steps=L):
+        q, p = q.clone(), p.clone()
+        lib.call("pbbi_leapfrog", pot.handle, q.data_ptr(), p.data_ptr(), None, N, N, hh, steps,
+                 stream_ptr(0))
+        return q, p
+
+    def energy(q, p):
+        H = empty((N,), np.float64, 0)
+        lib.call("pbbi_energy", pot.handle, q.data_ptr(), p.data_ptr(), None, N, N, H.data_ptr(),
+                 None, stream_ptr(0))
+        return H
+    q1, p1 = leap(q0, p0)
+    q1b, p1b = leap(q0, p0)
+    assert torch.equal(q1, q1b) and torch.equal(p1, p1b)                       # deterministic
+    qs, ps = leap(3.0 * q0, 3.0 * p0)                                          # linear flow (mu = 0)
+    assert float((qs - 3.0 * q1).abs().max() / q1.abs().max()) < 1e-13
+    qr, pr = leap(q1, -p1)                                                     # reversible
+    assert float((qr - q0).abs().max()) < 1e-11 and float((pr + p0).abs().max()) < 1e-11
+    dH = (energy(q1, p1) - energy(q0, p0)).abs()
+    q2, p2 = leap(q0, p0, h / 2, 2 * L)
+    dH2 = (energy(q2, p2) - energy(q0, p0)).abs()
+    assert 3.0 < float(dH.mean() / dH2.mean()) < 5.0                           # 2nd order: ~4x
