@@ -1,0 +1,603 @@
+// kernels_big.hip -- dense-precision Gaussian with D > 128 (fp64 and fp32), gfx950.
+//
+// BASELINE config 5 (D = 4096, fp32, 8192 chains): the precision matrix (64 MiB) no longer fits
+// LDS and the state of a chain (3 x 4096 values) no longer fits registers, so the trajectory is
+// a sequence of L+1 tiled MFMA GEMMs  G = P (Q - mu)  over the whole ensemble, each with the
+// leapfrog bookkeeping FUSED INTO ITS EPILOGUE (kick, drift into the other q buffer, partial
+// x.g sums for the potential energy).  State streams through HBM once per step:
+//     read q_j (GEMM operand + epilogue), read/write vh, write q_{j+1}
+// and the GEMM is MFMA-bound: 2 D^2 flop vs ~5 D w bytes per step*chain.
+//
+//   * A operand: P^T stored [k][i] (uploaded transposed and zero-padded to a multiple of 128),
+//     B operand: X = q - mu stored [k][n]  (the (D, N) state layout as it is).  Both tiles are
+//     therefore "k-major" with a contiguous inner dimension: global -> LDS is a straight,
+//     coalesced tile copy and the MFMA operand reads are lane-consecutive (conflict-free).
+//   * fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 flop/clk/SIMD = the f32 vector
+//     peak), 128 x 128 x 32 block tile, 4 waves as 2 x 2, each wave 2 x 2 tiles of 32 x 32.
+//     fp64: v_mfma_f64_16x16x4_f64, 128 x 128 x 16 block tile, each wave 4 x 4 tiles of 16 x 16.
+//   * Kick-drift-kick leapfrog (see kernels_dense.hip): epilogue of the GEMM on q_j does
+//         vh += -(g/m) * hk;   q_{j+1} = q_j + vh*h   (written to the other q buffer)
+//     first and last kicks are half kicks; the last epilogue does not drift.
+//   * Energies: per-chain sums over D are two-stage and deterministic (per-tile partials, then
+//     one ordered sum), never atomics: the accept decision must not depend on arrival order.
+//   * Block order: consecutive blockIdx sweep the P^T panels for ONE 128-chain panel of X, so
+//     that X panel (K x 128) stays hot while it is reused D/128 times; P^T (64 MiB at D=4096
+//     fp32) is re-read by every X panel and stays resident in the 256 MiB Infinity Cache.
+//
+// Leapfrog only; Stormer-Verlet and D > 128 fails loudly (PBBI_ERR_UNSUPPORTED).
+#include <vector>
+
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, NTHR = 256;
+
+template <typename T> struct Cfg;
+template <> struct Cfg<float> { static constexpr int BK = 32; };
+template <> struct Cfg<double> { static constexpr int BK = 16; };
+
+enum { EPI_EVAL = 0, EPI_KDK = 1 };
+
+template <typename T>
+struct GemmPrm {
+    const T* PT;      // DPAD x DPAD, [k][i], zero padded
+    const T* mu;      // DPAD, zero padded
+    const T* q;       // (D, N) operand, leading stride ldq
+    T* q_next;        // (D, N) drift target (ldw) or nullptr (no drift)
+    T* vh;            // (D, N) half-step velocity, updated in place (ldw); EPI_KDK
+    const T* minv;    // N: 1/m per chain, or nullptr (= 1)
+    T* grad_out;      // EPI_EVAL: (D, N) with stride ldg, or nullptr
+    T* xg_part;       // [DPAD/BM][N] partial sums of x*g over the tile's rows, or nullptr
+    int64_t N, ldq, ldw, ldg;
+    int D, DPAD;
+    T hk, h;
+};
+
+// ---- per-wave MFMA micro-kernels ---------------------------------------------------------------
+// As/Bs are [BK][BM] / [BK][BN] tiles in LDS.  wm/wn: this wave's 64 x 64 corner of the block.
+struct MmaF32 {
+    v16f32 acc[2][2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
+    __device__ __forceinline__ void tile(const float* As, const float* Bs, int wm, int wn, int lane) {
+        const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < Cfg<float>::BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(kk + kh) * BM + wm + 32 * t + r];  // A[i = r][k = kh]
+                b[t] = Bs[(kk + kh) * BN + wn + 32 * t + r];  // B[k = kh][n = r]
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+    // visit(i, n, tb, value): C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    template <typename F>
+    __device__ __forceinline__ void each(int wm, int wn, int lane, F&& f) const {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f(wm + 32 * ta + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wn + 32 * tb + (lane & 31),
+                      tb, acc[ta][tb][r]);
+    }
+};
+
+struct MmaF64 {
+    v4f64 acc[4][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    }
+    __device__ __forceinline__ void tile(const double* As, const double* Bs, int wm, int wn, int lane) {
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < Cfg<double>::BK; kk += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[(kk + kq) * BM + wm + 16 * t + r];  // A[i = r][k = kq]
+                b[t] = Bs[(kk + kq) * BN + wn + 16 * t + r];  // B[k = kq][n = r]
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+    // f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
+    template <typename F>
+    __device__ __forceinline__ void each(int wm, int wn, int lane, F&& f) const {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    f(wm + 16 * ta + (lane >> 4) + 4 * r, wn + 16 * tb + (lane & 15), tb, acc[ta][tb][r]);
+    }
+};
+
+template <typename T> struct MmaOf;
+template <> struct MmaOf<float> { using type = MmaF32; };
+template <> struct MmaOf<double> { using type = MmaF64; };
+
+// ---- the GEMM with fused epilogue ----------------------------------------------------------------
+template <typename T, int EPI>
+__global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
+    constexpr int BK = Cfg<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem_big[];
+    T (*As)[BK * BM] = reinterpret_cast<T (*)[BK * BM]>(smem_big);                      // [2]
+    T (*Bs)[BK * BN] = reinterpret_cast<T (*)[BK * BN]>(smem_big + 2 * BK * BM * sizeof(T));  // [2]
+    T (*red)[BN] = reinterpret_cast<T (*)[BN]>(smem_big + 4 * BK * BM * sizeof(T));    // [2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int n_tiles_m = prm.DPAD / BM;
+    const int bm = blockIdx.x % n_tiles_m, bn = blockIdx.x / n_tiles_m;  // a P^T panel's tiles are
+    const int i0 = bm * BM;                                              // consecutive: spread over XCDs
+    const int64_t n0 = (int64_t)bn * BN;
+
+    // staging map: element e = tid + 256*j of a BK x 128 tile -> (k = e / 128, x = e % 128)
+    constexpr int PER = BK * BM / NTHR;
+    T ra[PER], rb[PER];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = tid + NTHR * j, k = e >> 7, x = e & 127;
+            ra[j] = prm.PT[(size_t)(k0 + k) * prm.DPAD + i0 + x];
+            const int64_t n = n0 + x;
+            const bool ok = (k0 + k < prm.D) && (n < prm.N);
+            rb[j] = ok ? prm.q[(int64_t)(k0 + k) * prm.ldq + n] - prm.mu[k0 + k] : T(0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = tid + NTHR * j;
+            As[buf][e] = ra[j];
+            Bs[buf][e] = rb[j];
+        }
+    };
+
+    typename MmaOf<T>::type mma;
+    mma.zero();
+    const int nk = prm.DPAD / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) load_tiles((t + 1) * BK);  // global loads in flight under the MFMAs
+        mma.tile(As[cur], Bs[cur], wm, wn, lane);
+        if (t + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    // both C/D maps give a lane one fixed column per column-tile tb and several rows:
+    // accumulate x.g per tb, then combine the lanes that share the column
+    constexpr int NTB = sizeof(T) == 4 ? 2 : 4;
+    T xg[NTB];
+#pragma unroll
+    for (int b = 0; b < NTB; ++b) xg[b] = T(0);
+    mma.each(wm, wn, lane, [&](int il, int nl, int tb, T g) {
+        const int i = i0 + il;
+        const int64_t n = n0 + nl;
+        if (i < prm.D && n < prm.N) {
+            const T qv = prm.q[(int64_t)i * prm.ldq + n];
+            xg[tb] += (qv - prm.mu[i]) * g;
+            if constexpr (EPI == EPI_EVAL) {
+                if (prm.grad_out) prm.grad_out[(int64_t)i * prm.ldg + n] = g;
+            } else {
+                const T mi = prm.minv ? prm.minv[n] : T(1);
+                const int64_t o = (int64_t)i * prm.ldw + n;
+                const T v = prm.vh[o] + (-(g * mi)) * prm.hk;  // kick
+                prm.vh[o] = v;
+                if (prm.q_next) prm.q_next[o] = qv + v * prm.h;  // drift into the other buffer
+            }
+        }
+    });
+    if (prm.xg_part) {
+        // lanes that share a column: f32 map -> lanes l and l+32; f64 map -> l, l+16, l+32, l+48
+#pragma unroll
+        for (int b = 0; b < NTB; ++b) {
+            T s = xg[b];
+            if constexpr (sizeof(T) == 4) {
+                s += __shfl_xor(s, 32, 64);
+            } else {
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+            }
+            const int nl = wn + b * (sizeof(T) == 4 ? 32 : 16) + (lane & (sizeof(T) == 4 ? 31 : 15));
+            const bool writer = sizeof(T) == 4 ? (lane < 32) : (lane < 16);
+            if (writer) red[wave >> 1][nl] = s;
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < prm.N)
+            prm.xg_part[(size_t)bm * prm.N + n0 + tid] = red[0][tid] + red[1][tid];
+    }
+}
+
+// ---- elementwise helpers ---------------------------------------------------------------------------
+// column sums over row blocks: part[rb][n] = sum_{d in block rb} f(a[d][n]) with f = square.
+template <typename T>
+__global__ void k_big_sq_partial(const T* a, int64_t ld, int D, int64_t N, int rows_per_block,
+                                 T* part) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int d0 = blockIdx.y * rows_per_block;
+    const int d1 = d0 + rows_per_block < D ? d0 + rows_per_block : D;
+    T s = T(0);
+    for (int d = d0; d < d1; ++d) {
+        const T v = a[(int64_t)d * ld + n];
+        s += v * v;
+    }
+    part[(size_t)blockIdx.y * N + n] = s;
+}
+
+// momentum: p -> vh = p * minv (parity mode: p_in given) or Philox draw (p written to vh first).
+template <typename T>
+__global__ void k_big_momentum(const T* p_in, int64_t ldp, T* vh, T* p_keep, int64_t ldw, int D,
+                               int64_t N, const T* mass, int rng, uint64_t seed, uint64_t iter,
+                               uint64_t chain0, double kT) {
+    // one thread per (block of 4 dims sharing a Philox block, chain)
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y;  // Philox block index: dims 16*(blk>>2) + (blk&3) + 4*slot
+    if (n >= N) return;
+    const double m = mass ? (double)mass[n] : 1.0;
+    const double pstd = sqrt(m * kT);
+    float z[4];
+    if (rng) rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain0 + (uint64_t)n, (uint32_t)blk, z);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const int d = 16 * (blk >> 2) + (blk & 3) + 4 * sl;
+        if (d < D) {
+            const T p = rng ? (T)((double)z[sl] * pstd) : p_in[(int64_t)d * ldp + n];
+            if (p_keep) p_keep[(int64_t)d * ldw + n] = p;  // drawn momentum (needed for pp_old / rejects)
+            vh[(int64_t)d * ldw + n] = mass ? (T)(p * (T)(1.0 / m)) : p;
+        }
+    }
+}
+
+// decision: H_old, H_new from the partial sums; ratio; reject flag; uniform from Philox or u_in.
+template <typename T>
+__global__ void k_big_decide(const T* pp_old_part, const T* pp_new_part, int n_sq_parts,
+                             const T* xg_old_part, const T* xg_new_part, int n_xg_parts,
+                             const T* mass, const T* u_in, int rng, uint64_t seed, uint64_t iter,
+                             uint64_t chain0, T cst, int64_t N, T* ratio_out, uint8_t* reject) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    T po = T(0), pn = T(0), xo = T(0), xn = T(0);
+    for (int b = 0; b < n_sq_parts; ++b) {
+        po += pp_old_part[(size_t)b * N + n];
+        pn += pp_new_part[(size_t)b * N + n];
+    }
+    for (int b = 0; b < n_xg_parts; ++b) {
+        xo += xg_old_part[(size_t)b * N + n];
+        xn += xg_new_part[(size_t)b * N + n];
+    }
+    const T m = mass ? mass[n] : T(1);
+    const T oldH = T(0.5) * po / m + (T(0.5) * xo + cst);
+    const T newH = T(0.5) * pn / m + (T(0.5) * xn + cst);
+    const T ratio = exp(oldH - newH);
+    const T u = rng ? (T)rng_uniform(seed, iter, chain0 + (uint64_t)n) : u_in[n];
+    const bool rej = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+    reject[n] = rej ? 1 : 0;
+    if (ratio_out) ratio_out[n] = ratio;
+}
+
+// p_new = v_L * m (into pbuf, in place) -- used before the pp_new reduction
+template <typename T>
+__global__ void k_big_v_to_p(T* v, int64_t ld, int D, int64_t N, const T* mass) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (n < N && d < D && mass) v[(int64_t)d * ld + n] *= mass[n];
+}
+
+// select: q_out = reject ? q_old : q_new;  p_out = reject ? (compat ? q_old : p_draw) : p_new
+template <typename T>
+__global__ void k_big_select(const T* q_old, int64_t ldq, const T* q_new, const T* p_new,
+                             const T* p_draw, int64_t ldw, const uint8_t* reject, int compat,
+                             T* q_out, T* p_out, int64_t ldo, int D, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (n >= N || d >= D) return;
+    const bool rej = reject[n] != 0;
+    const T qo = q_old[(int64_t)d * ldq + n];
+    q_out[(int64_t)d * ldo + n] = rej ? qo : q_new[(int64_t)d * ldw + n];
+    if (p_out)
+        p_out[(int64_t)d * ldo + n] =
+            rej ? (compat ? qo : p_draw[(int64_t)d * ldw + n]) : p_new[(int64_t)d * ldw + n];
+}
+
+template <typename T>
+__global__ void k_big_copy(const T* src, int64_t lds, T* dst, int64_t ldd, int D, int64_t N, T scale,
+                           const T* scale_n) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (n < N && d < D)
+        dst[(int64_t)d * ldd + n] = src[(int64_t)d * lds + n] * (scale_n ? scale_n[n] : scale);
+}
+
+template <typename T>
+__global__ void k_big_finish_eval(const T* xg_part, int n_parts, const T* pp_part, int n_sq_parts,
+                                  const T* mass, T cst, int64_t N, T* U_out, T* w_out, int mode) {
+    // mode 0: U_out = 0.5 xg + cst; 1: H (and w = exp(-H)); 2: U_out = exp(U_out - H)
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    T xg = T(0), pp = T(0);
+    for (int b = 0; b < n_parts; ++b) xg += xg_part[(size_t)b * N + n];
+    const T U = T(0.5) * xg + cst;
+    if (mode == 0) {
+        if (U_out) U_out[n] = U;
+        return;
+    }
+    for (int b = 0; b < n_sq_parts; ++b) pp += pp_part[(size_t)b * N + n];
+    const T H = T(0.5) * pp / (mass ? mass[n] : T(1)) + U;
+    if (mode == 1) {
+        if (U_out) U_out[n] = H;
+        if (w_out) w_out[n] = exp(-H);
+    } else {
+        U_out[n] = exp(U_out[n] - H);
+    }
+}
+
+template <typename T>
+__global__ void k_big_inv(const T* mass, T* minv, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) minv[n] = T(1) / mass[n];
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+struct Workspace {  // stream-ordered scratch for one call
+    hipStream_t st;
+    std::vector<void*> ptrs;
+    explicit Workspace(hipStream_t s) : st(s) {}
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMallocAsync(&p, bytes ? bytes : 16, st) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+    ~Workspace() {
+        for (void* p : ptrs) (void)hipFreeAsync(p, st);
+    }
+};
+
+constexpr int SQ_ROWS = 256;  // rows per block of the p^2 column reduction
+
+template <typename T>
+int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next, T* vh, int64_t ldw,
+         const T* minv, T* grad_out, int64_t ldg, T* xg_part, int64_t N, T hk, T h, hipStream_t st) {
+    GemmPrm<T> prm{(const T*)pot->d_big_PT, (const T*)pot->d_big_mu, q, q_next, vh, minv, grad_out,
+                   xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h};
+    const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
+    const size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
+    if (epi == EPI_EVAL) {
+        PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_gemm<T, EPI_EVAL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_big_gemm<T, EPI_EVAL>), dim3(tiles), dim3(NTHR), lds, st, prm);
+    } else {
+        PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_gemm<T, EPI_KDK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_big_gemm<T, EPI_KDK>), dim3(tiles), dim3(NTHR), lds, st, prm);
+    }
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+inline dim3 grid2d(int64_t N, int D) { return dim3((unsigned)((N + 255) / 256), (unsigned)D); }
+
+template <typename T>
+int run_hmc(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    const int D = pot->D, L = a.L;
+    const int64_t N = a.N;
+    hipStream_t st = a.stream;
+    Workspace ws(st);
+    const size_t slab = (size_t)D * N * sizeof(T);
+    const int n_xg = pot->DPAD_big / BM, n_sq = (D + SQ_ROWS - 1) / SQ_ROWS;
+    T* vh = (T*)ws.get(slab);
+    T* qa = (T*)ws.get(slab);
+    T* qb = (T*)ws.get(slab);
+    T* pdraw = (T*)ws.get(slab);
+    T* xg_old = (T*)ws.get((size_t)n_xg * N * sizeof(T));
+    T* xg_new = (T*)ws.get((size_t)n_xg * N * sizeof(T));
+    T* pp_old = (T*)ws.get((size_t)n_sq * N * sizeof(T));
+    T* pp_new = (T*)ws.get((size_t)n_sq * N * sizeof(T));
+    uint8_t* rej = a.reject_out ? a.reject_out : (uint8_t*)ws.get((size_t)N);
+    T* minv = a.mass ? (T*)ws.get((size_t)N * sizeof(T)) : nullptr;
+    if (!vh || !qa || !qb || !pdraw || !xg_old || !xg_new || !pp_old || !pp_new || !rej ||
+        (a.mass && !minv))
+        return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the large-D workspace");
+    const dim3 b1(256), g1((unsigned)((N + 255) / 256));
+    if (minv) hipLaunchKernelGGL(k_big_inv<T>, g1, b1, 0, st, (const T*)a.mass, minv, N);
+    // momentum (drawn or uploaded) -> pdraw, vh = p/m; pp_old partials
+    const int n_blk = ((D + 15) / 16) * 4;
+    hipLaunchKernelGGL(k_big_momentum<T>, dim3(g1.x, (unsigned)n_blk), b1, 0, st, (const T*)a.p_in,
+                       a.ldn_in, vh, pdraw, N, D, N, (const T*)a.mass, a.rng, a.seed, a.iter,
+                       a.chain0, a.kT);
+    hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)pdraw,
+                       (int64_t)N, D, N, SQ_ROWS, pp_old);
+    const T h = (T)a.h, hh = (T)(0.5 * a.h);
+    // L + 1 GEMMs; q_0 is the caller's q_in, then ping-pong between qa and qb
+    const T* qcur = (const T*)a.q_in;
+    int64_t ldcur = a.ldn_in;
+    for (int j = 0; j <= L; ++j) {
+        const bool first = (j == 0), last = (j == L);
+        T* qnext = last ? nullptr : ((j & 1) ? qb : qa);
+        if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0,
+                             first ? xg_old : (last ? xg_new : nullptr), N,
+                             (first || last) ? hh : h, h, st))
+            return rc;
+        if (L == 0) break;  // single evaluation: q does not move, xg_new = xg_old
+        if (!last) { qcur = qnext; ldcur = N; }
+    }
+    // NOTE: with L == 0 the "first" epilogue applied a half kick; the reference leaves p untouched.
+    // L == 0 is rejected by the caller (big_hmc_iter) for this path.
+    hipLaunchKernelGGL(k_big_v_to_p<T>, grid2d(N, D), b1, 0, st, vh, (int64_t)N, D, N, (const T*)a.mass);
+    hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)vh,
+                       (int64_t)N, D, N, SQ_ROWS, pp_new);
+    hipLaunchKernelGGL(k_big_decide<T>, g1, b1, 0, st, (const T*)pp_old, (const T*)pp_new, n_sq,
+                       (const T*)xg_old, (const T*)xg_new, n_xg, (const T*)a.mass, (const T*)a.u_in,
+                       a.rng, a.seed, a.iter, a.chain0, (T)pot->cst, N, (T*)a.ratio_out, rej);
+    hipLaunchKernelGGL(k_big_select<T>, grid2d(N, D), b1, 0, st, (const T*)a.q_in, a.ldn_in, qcur,
+                       (const T*)vh, (const T*)pdraw, (int64_t)N, (const uint8_t*)rej,
+                       (a.flags & PBBI_COMPAT_P_FROM_OLDQ) ? 1 : 0, (T*)a.q_out, (T*)a.p_out,
+                       a.ldn_out, D, N);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+template <typename T>
+int run_integrate(const IntegrateArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    const int D = pot->D, L = a.L;
+    const int64_t N = a.N;
+    hipStream_t st = a.stream;
+    Workspace ws(st);
+    const size_t slab = (size_t)D * N * sizeof(T);
+    T* vh = (T*)ws.get(slab);
+    T* qa = (T*)ws.get(slab);
+    T* qb = (T*)ws.get(slab);
+    T* minv = a.mass ? (T*)ws.get((size_t)N * sizeof(T)) : nullptr;
+    if (!vh || !qa || !qb || (a.mass && !minv))
+        return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the large-D workspace");
+    const dim3 b1(256), g1((unsigned)((N + 255) / 256));
+    if (minv) hipLaunchKernelGGL(k_big_inv<T>, g1, b1, 0, st, (const T*)a.mass, minv, N);
+    // vh = p * (1/m)
+    hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, (const T*)a.p, a.ldn, vh, (int64_t)N, D,
+                       N, T(1), (const T*)minv);
+    const T h = (T)a.h, hh = (T)(0.5 * a.h);
+    const T* qcur = (const T*)a.q;
+    int64_t ldcur = a.ldn;
+    for (int j = 0; j <= L && L > 0; ++j) {
+        const bool first = (j == 0), last = (j == L);
+        T* qnext = last ? nullptr : ((j & 1) ? qb : qa);
+        if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0, nullptr, N,
+                             (first || last) ? hh : h, h, st))
+            return rc;
+        if (!last) { qcur = qnext; ldcur = N; }
+    }
+    if (a.v_out)
+        hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, (const T*)vh, (int64_t)N,
+                           (T*)a.v_out, a.ldn, D, N, T(1), (const T*)nullptr);
+    if (qcur != (const T*)a.q)
+        hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, qcur, (int64_t)N, (T*)a.q, a.ldn, D,
+                           N, T(1), (const T*)nullptr);
+    hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, (const T*)vh, (int64_t)N, (T*)a.p, a.ldn,
+                       D, N, T(1), (const T*)a.mass);  // p = v*m
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+template <typename T>
+int run_eval(const EvalArgs& a, int mode) {
+    const pbbi_potential* pot = a.pot;
+    const int D = pot->D;
+    const int64_t N = a.N;
+    hipStream_t st = a.stream;
+    Workspace ws(st);
+    const int n_xg = pot->DPAD_big / BM, n_sq = (D + SQ_ROWS - 1) / SQ_ROWS;
+    T* xg = (T*)ws.get((size_t)n_xg * N * sizeof(T));
+    T* pp = mode ? (T*)ws.get((size_t)n_sq * N * sizeof(T)) : nullptr;
+    if (!xg || (mode && !pp))
+        return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the large-D workspace");
+    if (int rc = gemm<T>(pot, EPI_EVAL, (const T*)a.q, a.ldn, nullptr, nullptr, 0, nullptr,
+                         (T*)a.grad_out, a.ldn, xg, N, T(0), T(0), st))
+        return rc;
+    const dim3 b1(256), g1((unsigned)((N + 255) / 256));
+    if (mode)
+        hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)a.p,
+                           a.ldn, D, N, SQ_ROWS, pp);
+    hipLaunchKernelGGL(k_big_finish_eval<T>, g1, b1, 0, st, (const T*)xg, n_xg, (const T*)pp, n_sq,
+                       (const T*)a.mass, (T)pot->cst, N, (T*)a.U_out, (T*)a.w_out, mode);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int check(const pbbi_potential* pot) {
+    if (!pot->d_big_PT)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "large-D dense path was not built for this handle");
+    return PBBI_OK;
+}
+
+}  // namespace
+
+// P^T, zero padded to DPAD x DPAD (DPAD multiple of 128), and mu padded; dtype of the handle.
+int big_build(pbbi_potential* pot, const double* P, const double* mean) {
+    const int D = pot->D;
+    const int DPAD = ((D + BM - 1) / BM) * BM;
+    pot->DPAD_big = DPAD;
+    const size_t es = pot->dtype == PBBI_F64 ? 8 : 4;
+    std::vector<char> buf((size_t)DPAD * DPAD * es, 0), mub((size_t)DPAD * es, 0);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            const double v = P[(size_t)i * D + k];  // PT[k][i] = P[i][k]
+            if (es == 8) ((double*)buf.data())[(size_t)k * DPAD + i] = v;
+            else ((float*)buf.data())[(size_t)k * DPAD + i] = (float)v;
+        }
+    for (int d = 0; d < D; ++d) {
+        const double v = mean ? mean[d] : 0.0;
+        if (es == 8) ((double*)mub.data())[d] = v;
+        else ((float*)mub.data())[d] = (float)v;
+    }
+    PBBI_HIP(hipMalloc(&pot->d_big_PT, buf.size()));
+    PBBI_HIP(hipMalloc(&pot->d_big_mu, mub.size()));
+    PBBI_HIP(hipMemcpy(pot->d_big_PT, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    PBBI_HIP(hipMemcpy(pot->d_big_mu, mub.data(), mub.size(), hipMemcpyHostToDevice));
+    return PBBI_OK;
+}
+
+int big_hmc_iter(const IterArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.method != PBBI_LEAPFROG)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: Leapfrog only in this build");
+    if (a.L < 1)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: numSteps must be >= 1");
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? run_hmc<double>(a) : run_hmc<float>(a);
+}
+
+int big_integrate(const IntegrateArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.method != PBBI_LEAPFROG)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: Leapfrog only in this build");
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? run_integrate<double>(a) : run_integrate<float>(a);
+}
+
+int big_eval(const EvalArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    return a.pot->dtype == PBBI_F64 ? run_eval<double>(a, 0) : run_eval<float>(a, 0);
+}
+
+int big_energy(const EvalArgs& a) {
+    if (int rc = check(a.pot)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    const int mode = a.ratio_finish ? 2 : 1;
+    return a.pot->dtype == PBBI_F64 ? run_eval<double>(a, mode) : run_eval<float>(a, mode);
+}

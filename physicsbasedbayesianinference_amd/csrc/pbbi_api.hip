@@ -51,8 +51,10 @@ int new_handle(int kind, int D, int dtype, int device, pbbi_potential** out) {
     if (!p) return pbbi_fail(PBBI_ERR_INVALID, "out of host memory");
     p->kind = kind; p->D = D; p->dtype = dtype; p->device = device;
     p->cst = 0.0; p->a = 1.0; p->b = 100.0; p->s = 20.0;
-    p->d_mean = p->d_prec = p->d_frag = p->d_mean_pad = nullptr;
+    p->d_mean = p->d_prec = p->d_frag = p->d_mean_pad = p->d_big_PT = p->d_big_mu = nullptr;
     p->DP = 0;
+    p->DPAD_big = 0;
+    p->zero_mean = true;
     *out = p;
     return PBBI_OK;
 }
@@ -80,7 +82,12 @@ int check_common(const pbbi_potential* pot, int64_t N, int64_t ldn) {
     return PBBI_OK;
 }
 
-inline bool is_dense(const pbbi_potential* pot) { return pot->kind == KIND_GAUSS_DENSE; }
+inline bool is_dense(const pbbi_potential* pot) {  // register-resident MFMA path
+    return pot->kind == KIND_GAUSS_DENSE && pot->DP != 0;
+}
+inline bool is_big(const pbbi_potential* pot) {  // streaming GEMM path
+    return pot->kind == KIND_GAUSS_DENSE && pot->DP == 0;
+}
 
 // ---- small utility kernels ---------------------------------------------------
 template <typename T>
@@ -178,7 +185,9 @@ int pbbi_potential_create_gauss_dense(int D, const double* mean, const double* p
     (*out)->cst = cst;
     int rc = upload(precision, (size_t)D * D, dtype, &(*out)->d_prec);
     if (rc == PBBI_OK) rc = upload_mean(*out, mean);
+    // D <= 128 in fp64: register-resident MFMA kernels; otherwise the streaming GEMM path
     if (rc == PBBI_OK) rc = dense_build_fragments(*out, precision, mean);
+    if (rc == PBBI_OK && (*out)->DP == 0) rc = big_build(*out, precision, mean);
     return finish_or_destroy(rc, out);
 }
 
@@ -193,7 +202,7 @@ int pbbi_potential_create_rosenbrock(int D, double a, double b, double s, int dt
 int pbbi_potential_destroy(pbbi_potential* pot) {
     if (!pot) return PBBI_OK;
     DeviceGuard guard(pot->device);
-    for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad})
+    for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad, pot->d_big_PT, pot->d_big_mu})
         if (p) (void)hipFree(p);
     delete pot;
     return PBBI_OK;
@@ -209,7 +218,7 @@ int pbbi_potential_eval(const pbbi_potential* pot, const void* q, int64_t N, int
     if (!q && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q is NULL");
     DeviceGuard guard(pot->device);
     EvalArgs a{pot, q, nullptr, nullptr, N, ldn, U_out, grad_out, nullptr, 0, (hipStream_t)stream};
-    return is_dense(pot) ? dense_eval(a) : lane_eval(a);
+    return is_big(pot) ? big_eval(a) : is_dense(pot) ? dense_eval(a) : lane_eval(a);
 }
 
 // ==================================================================== integrators
@@ -222,7 +231,7 @@ int pbbi_integrate(const pbbi_potential* pot, int method, void* q, void* p, cons
     if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
     DeviceGuard guard(pot->device);
     IntegrateArgs a{pot, method, q, p, mass, v_out, N, ldn, h, L, (hipStream_t)stream};
-    return is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
+    return is_big(pot) ? big_integrate(a) : is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
 }
 
 int pbbi_leapfrog(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
@@ -242,7 +251,7 @@ int pbbi_energy(const pbbi_potential* pot, const void* q, const void* p, const v
     if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
     DeviceGuard guard(pot->device);
     EvalArgs a{pot, q, p, mass, N, ldn, H_out, nullptr, weight_out, 0, (hipStream_t)stream};
-    return is_dense(pot) ? dense_energy(a) : lane_energy(a);
+    return is_big(pot) ? big_energy(a) : is_dense(pot) ? dense_energy(a) : lane_energy(a);
 }
 
 int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* newP,
@@ -255,9 +264,9 @@ int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* 
     DeviceGuard guard(pot->device);
     // pass 1: ratio_out <- oldH ; pass 2: ratio_out <- exp(ratio_out - newH)   (src/HMC.py:109-115)
     EvalArgs a{pot, oldQ, oldP, mass, N, ldn, ratio_out, nullptr, nullptr, 0, (hipStream_t)stream};
-    if (int rc = is_dense(pot) ? dense_energy(a) : lane_energy(a)) return rc;
+    if (int rc = is_big(pot) ? big_energy(a) : is_dense(pot) ? dense_energy(a) : lane_energy(a)) return rc;
     EvalArgs b{pot, newQ, newP, mass, N, ldn, ratio_out, nullptr, nullptr, 1, (hipStream_t)stream};
-    return is_dense(pot) ? dense_energy(b) : lane_energy(b);
+    return is_big(pot) ? big_energy(b) : is_dense(pot) ? dense_energy(b) : lane_energy(b);
 }
 
 // ================================================================ HMC iteration(s)
@@ -282,7 +291,7 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
     a.q_out = q_out; a.p_out = p_out; a.ratio_out = ratio_out; a.reject_out = reject_out;
     a.N = N; a.ldn_in = ldn; a.ldn_out = ldn; a.h = h; a.L = L; a.flags = flags;
     a.rng = 0; a.kT = 1.0; a.stream = (hipStream_t)stream;
-    return is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
+    return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
 }
 
 int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
@@ -312,7 +321,8 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         a.N = N; a.h = h; a.L = L; a.flags = flags;
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = (hipStream_t)stream;
-        if (int rc = is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a)) return rc;
+        if (int rc = is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a))
+            return rc;
     }
     // leave the chain state in q_state (strided D2D copy of the last slab)
     PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * es,

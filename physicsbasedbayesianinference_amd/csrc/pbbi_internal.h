@@ -22,6 +22,10 @@ struct pbbi_potential {
     void* d_frag;  // DP*DP elements: precision in MFMA A-fragment order
     void* d_mean_pad;  // DP elements, zero padded
     bool zero_mean;    // every mean entry is exactly 0 (x = q, no subtraction needed)
+    // dense Gaussian, streaming GEMM path (D > 128, or fp32): kernels_big.hip
+    int DPAD_big;      // D padded to a multiple of 128 (0 = path not built)
+    void* d_big_PT;    // DPAD x DPAD, P transposed ([k][i]), zero padded, handle dtype
+    void* d_big_mu;    // DPAD, zero padded
 };
 
 // ---- error plumbing ---------------------------------------------------------
@@ -107,3 +111,9 @@ int dense_integrate(const IntegrateArgs& a);
 int dense_eval(const EvalArgs& a);
 int dense_energy(const EvalArgs& a);
 int dense_build_fragments(pbbi_potential* pot, const double* precision_host, const double* mean_host);
+// dense-precision Gaussian, streaming MFMA GEMM per step (D > 128, fp64 / fp32), kernels_big.hip
+int big_hmc_iter(const IterArgs& a);
+int big_integrate(const IntegrateArgs& a);
+int big_eval(const EvalArgs& a);
+int big_energy(const EvalArgs& a);
+int big_build(pbbi_potential* pot, const double* precision_host, const double* mean_host);

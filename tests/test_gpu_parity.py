@@ -506,3 +506,109 @@ def test_full_size_properties_c2(P, lib):
     q2, p2 = leap(q0, p0, h / 2, 2 * L)
     dH2 = (energy(q2, p2) - energy(q0, p0)).abs()
     assert 3.0 < float(dH.mean() / dH2.mean()) < 5.0                           # 2nd order: ~4x
+
+
+# ------------------------------------------------------------------ large-D dense path (streaming GEMM)
+def _dense_problem(D, seed=0):
+    rs = np.random.RandomState(seed)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    return 0.5 * (Pm + Pm.T), rs.standard_normal(D) * 0.5
+
+
+@pytest.mark.parametrize("D,N,dtype,tol", [(200, 150, "float64", 1e-12), (256, 130, "float64", 1e-12),
+                                           (384, 70, "float32", 2e-5)])
+def test_big_dense_eval_vs_oracle(P, D, N, dtype, tol):
+    Pm, mu = _dense_problem(D)
+    pot = P.GaussianDense(mu, precision=Pm, const=0.25, dtype=dtype)
+    q = np.random.RandomState(1).standard_normal((D, N))
+    U, g = pot.value_and_gradient(q)
+    Uo, go = orc.potential(orc.pot_gauss_dense(mu, Pm, 0.25), q, want_grad=True)
+    assert scaled_err(g, go) <= tol and scaled_err(U, Uo) <= tol * 10
+
+
+def test_big_dense_asymmetric_matrix_layout(P):
+    """P^T is what the kernel reads: a non-symmetric matrix must still give grad = P x."""
+    D, N = 160, 40
+    rs = np.random.RandomState(2)
+    M = rs.standard_normal((D, D)) / np.sqrt(D)
+    pot = P.GaussianDense(None, precision=M, const=0.0, symmetrize=False)
+    q = rs.standard_normal((D, N))
+    assert scaled_err(pot.gradient(q), M @ q) <= 1e-13
+
+
+@pytest.mark.parametrize("D,mass", [(192, False), (300, True)])
+def test_big_dense_integrate_vs_oracle(P, D, mass):
+    Pm, mu = _dense_problem(D, 3)
+    N = 90
+    pot = P.GaussianDense(mu, precision=Pm, const=0.0)
+    rs = np.random.RandomState(4)
+    ens = P.Ensemble(D, N)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    if mass:
+        ens.mass = m.copy()
+    ens.q[...] = rs.standard_normal((D, N))
+    ens.p[...] = rs.standard_normal((D, N))
+    qo, po = ens.q.copy(), ens.p.copy()
+    integ = P.Leapfrog(ens, 0.1, 1.0, pot)
+    q, p = integ.integrate()
+    vo = orc.integrate(orc.pot_gauss_dense(mu, Pm), "Leapfrog", qo, po, m, 0.1, 10)
+    assert scaled_err(q, qo) <= RTOL_DENSE and scaled_err(p, po) <= RTOL_DENSE
+    assert scaled_err(integ.v, vo) <= RTOL_DENSE
+    with pytest.raises(Exception):  # Stormer-Verlet is not built for D > 128: fails loudly
+        P.StormerVerlet(ens, 0.1, 1.0, pot).integrate()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_big_dense_getsamples_vs_oracle(P, lib, rng):
+    D, N, S, L, h = 256, 140, 3, 10, 0.1
+    Pm, mu = _dense_problem(D, 5)
+    pot, op = P.GaussianDense(mu, precision=Pm, const=0.0), orc.pot_gauss_dense(mu, Pm)
+    m = 1.0 + (np.arange(N) % 2) * 0.5
+    ens = P.Ensemble(D, N)
+    ens.mass = m.copy()
+    np.random.seed(21)
+    hmc = P.HMC(ens, 1.0, h, None, potential=pot, rng=rng, seed=6, verbose=False)
+    samples, momenta = hmc.getSamples(S, 1 / kB, 1.0, chain0=50)
+    if rng == "numpy":
+        ref = orc.get_samples_numpy_stream(op, "Leapfrog", D, N, S, 1.0, h, 1 / kB, 1.0, 21, mass=m)
+        assert np.array_equal(hmc.reject_masks, ref["reject_mask"])
+        assert scaled_err(samples, ref["samples"]) <= RTOL_DENSE
+        assert scaled_err(momenta, ref["momenta"]) <= RTOL_DENSE
+    else:
+        q = device_normal(lib, 6, lib.STREAM_POSITION, 0, 50, D, N, 1.0)
+        for i in range(S):
+            p = device_normal(lib, 6, lib.STREAM_MOMENTUM, i, 50, D, N, 1.0, np.sqrt(m))
+            u = device_uniform(lib, 6, i, 50, N)
+            _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+            assert np.array_equal(hmc.reject_masks[i], rej)
+            assert scaled_err(samples[:, :, i], q) <= RTOL_DENSE
+            assert scaled_err(momenta[:, :, i], p) <= RTOL_DENSE
+
+
+def test_c5_shape_fp32_vs_fp64_oracle(P, lib):
+    """BASELINE config 5's shape at small N: D = 4096 dense precision in fp32, h = 0.05, L = 10,
+    against the fp64 oracle.  fp32 MFMA accumulates 4096-term dot products in single precision:
+    tolerance 2e-4 scaled; decisions must agree wherever |log u - log ratio| > 1e-2."""
+    D, N, L, h = 4096, 64, 10, 0.05
+    Pm, _ = _dense_problem(D, 0)
+    pot = P.GaussianDense(None, precision=Pm, const=0.0, dtype="float32")
+    rs = np.random.RandomState(9)
+    q0 = rs.standard_normal((D, N)).astype(np.float32).astype(np.float64)
+    p0 = rs.standard_normal((D, N)).astype(np.float32).astype(np.float64)
+    u = rs.uniform(size=N).astype(np.float32).astype(np.float64)
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    import torch
+    qd, pd, ud = (as_device(x, 0, np.float32) for x in (q0, p0, u))
+    qo, po = empty((D, N), np.float32, 0), empty((D, N), np.float32, 0)
+    ro, rj = empty((N,), np.float32, 0), empty((N,), np.uint8, 0)
+    lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(), None,
+             qo.data_ptr(), po.data_ptr(), ro.data_ptr(), rj.data_ptr(), N, N, h, L, 1, stream_ptr(0))
+    torch.cuda.synchronize()
+    qr, pr = q0.copy(), p0.copy()
+    ratio, rej = orc.hmc_iter(orc.pot_gauss_dense(np.zeros(D), Pm), "Leapfrog", qr, pr, u, None, h, L)
+    assert scaled_err(to_numpy(qo).astype(np.float64), qr) <= 2e-4
+    assert scaled_err(to_numpy(po).astype(np.float64), pr) <= 2e-4
+    clear = np.abs(np.log(u) - np.minimum(0.0, np.log(ratio))) > 1e-2
+    assert clear.sum() > N // 2
+    assert np.array_equal(to_numpy(rj).astype(bool)[clear], rej[clear])
