@@ -137,6 +137,48 @@ def main_c3(args):
                      "launch_ms": ks * 1e3}}))
 
 
+def main_c5(args):
+    """BASELINE config 5: d=4096 dense-precision Gaussian, 8192 chains, fp32, h=0.05, L=10:
+    L+1 fused MFMA GEMMs per HMC iteration (kernels_big.hip).  MFMA-bound."""
+    import torch
+    import physicsbasedbayesianinference_amd as P
+    from physicsbasedbayesianinference_amd import _lib
+    d, N, h, L = 4096, 8192 if args.chains == N_PER_GPU else args.chains, 0.05, 10
+    K, W = min(args.steps, 20), min(args.warmup, 2)
+    pot = P.GaussianDense(None, precision=precision_matrix(d), const=0.0, dtype="float32")
+    stream = torch.cuda.current_stream().cuda_stream
+    q = torch.empty((d, N), dtype=torch.float32, device="cuda")
+    _lib.call("pbbi_philox_normal", 7, _lib.STREAM_POSITION, 0, 0, d, N, N, 1.0, None, _lib.F32, 0,
+              q.data_ptr(), stream)
+    S_alloc = max(K, W, 1)
+    samples = torch.empty((S_alloc, d, N), dtype=torch.float32, device="cuda")
+    momenta = torch.empty((S_alloc, d, N), dtype=torch.float32, device="cuda")
+    reject = torch.empty((S_alloc, N), dtype=torch.uint8, device="cuda")
+
+    def run(S, it0):
+        _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
+                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, 1, 7, it0, 0, 1.0, stream)
+    run(W, 0)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(); run(K, W); ev1.record()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    it_s = ev0.elapsed_time(ev1) * 1e-3 / K
+    flops_it = 2.0 * d * d * (L + 1) * N
+    print(json.dumps({
+        "metric": "leapfrog-steps*chains/sec; d=4096 dense Gaussian fp32, ensemble=8192 (config C5)",
+        "value": K * L * N / t, "unit": "leapfrog-steps*chains/s", "n_gpus": 1, "steps": K,
+        "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C5: d=4096 dense precision, 8192 chains, fp32, L=10, h=0.05",
+                   "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
+        "roofline": {"bound": "mfma", "kernel": "k_big_gemm<float, KDK> x (L+1) per iteration",
+                     "achieved": flops_it / it_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": flops_it / it_s / 1e12 / 157.3, "traffic": None,
+                     "iteration_ms": it_s * 1e3}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,12 +186,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chains", type=int, default=N_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the BASELINE metric) or c3 (Rosenbrock d=32, 262144 chains: "
                          "the HBM-bound chain-per-lane kernel; extra, not the headline line)")
     args = ap.parse_args()
     if args.workload == "c3":
         return main_c3(args)
+    if args.workload == "c5":
+        return main_c5(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

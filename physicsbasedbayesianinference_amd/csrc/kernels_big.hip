@@ -159,25 +159,44 @@ __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
     const int i0 = bm * BM;                                              // consecutive: spread over XCDs
     const int64_t n0 = (int64_t)bn * BN;
 
-    // staging map: element e = tid + 256*j of a BK x 128 tile -> (k = e / 128, x = e % 128)
-    constexpr int PER = BK * BM / NTHR;
-    T ra[PER], rb[PER];
+    // staging map: 16-byte chunk c = tid + 256*j of a BK x 128 tile -> (k = c / CPR, x = VEC*(c % CPR)),
+    // VEC elements per chunk, CPR = 128/VEC chunks per tile row: every wave instruction moves
+    // whole 128-B..1-KiB row segments (coalesced), one global_load_dwordx4 per chunk.
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CPR = BM / VEC;
+    constexpr int NCH = BK * BM / VEC / NTHR;  // chunks per thread per tile (4)
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    // X rows may only be read 16 B at a time when the row stride keeps them aligned and the
+    // whole chunk is inside N; otherwise fall back to element loads for that chunk.
+    const bool q_vec_ok = (prm.ldq % VEC == 0) && ((reinterpret_cast<uintptr_t>(prm.q) & 15) == 0);
+    vecT ra[NCH], rb[NCH];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = tid + NTHR * j, k = e >> 7, x = e & 127;
-            ra[j] = prm.PT[(size_t)(k0 + k) * prm.DPAD + i0 + x];
+        for (int j = 0; j < NCH; ++j) {
+            const int c = tid + NTHR * j, k = c / CPR, x = (c % CPR) * VEC;
+            ra[j] = *reinterpret_cast<const vecT*>(prm.PT + (size_t)(k0 + k) * prm.DPAD + i0 + x);
             const int64_t n = n0 + x;
-            const bool ok = (k0 + k < prm.D) && (n < prm.N);
-            rb[j] = ok ? prm.q[(int64_t)(k0 + k) * prm.ldq + n] - prm.mu[k0 + k] : T(0);
+            const int kr = k0 + k;
+            vecT v;
+            if (kr < prm.D && q_vec_ok && n + VEC <= prm.N) {
+                v = *reinterpret_cast<const vecT*>(prm.q + (int64_t)kr * prm.ldq + n);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    v[e] = (kr < prm.D && n + e < prm.N) ? prm.q[(int64_t)kr * prm.ldq + n + e] : T(0);
+            }
+            const T m = kr < prm.D ? prm.mu[kr] : T(0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (kr < prm.D && n + e < prm.N) ? v[e] - m : T(0);
+            rb[j] = v;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = tid + NTHR * j;
-            As[buf][e] = ra[j];
-            Bs[buf][e] = rb[j];
+        for (int j = 0; j < NCH; ++j) {
+            const int c = tid + NTHR * j;
+            *reinterpret_cast<vecT*>(&As[buf][c * VEC]) = ra[j];
+            *reinterpret_cast<vecT*>(&Bs[buf][c * VEC]) = rb[j];
         }
     };
 
