@@ -131,7 +131,7 @@ def main_c3(args):
         "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C3: Rosenbrock d=32, 262144 chains, L=10, h=0.01",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "hbm", "kernel": "k_lane_hmc<double, Rosenbrock, 32, LEAPFROG>",
+        "roofline": {"bound": "hbm", "kernel": "k_ros2_hmc<unit mass, D=32> (two lanes per chain)",
                      "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "launch_ms": ks * 1e3}}))

@@ -11,6 +11,7 @@
 //   StormerVerlet.integrate   src/integrator.py:142-163
 //   H = 0.5*dot(p,p)/m + U    src/HMC.py:100-102,109-115
 //   accept/reject + stores    src/HMC.py:164-179
+#include <cstdlib>
 #include <type_traits>
 
 #include "pbbi_buf.h"
@@ -58,49 +59,43 @@ struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
 };
 
 template <typename T, int DMAX, bool FULL>
-struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t = q_{i+1} - q_i^2
-    T a, b, inv_s, cst;
+struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t_i = fma(-q_i, q_i, q_{i+1})
+    // The build's own potential (not in the reference): constants pre-combined and fused
+    // multiply-adds are part of its DEFINITION (oracle/pbbi_oracle.c::pot_grad restates it with
+    // the same fma calls), because this kernel is bound by its fp64 instruction count.
+    T a, b, inv_s, cst, c1, c2, c3;  // c1 = (-4b)/s, c2 = 2/s, c3 = (2b)/s
     int D;
     __device__ __forceinline__ T U(const T (&q)[DMAX]) const {
         T s1 = T(0), s2 = T(0);
 #pragma unroll
         for (int i = 0; i + 1 < DMAX; ++i)
             if (FULL || i + 1 < D) {
-                const T t = q[i + 1] - q[i] * q[i];
-                s1 += (b * t) * t;
+                const T t = fma(-q[i], q[i], q[i + 1]);
+                s1 = fma(b * t, t, s1);
             }
 #pragma unroll
         for (int i = 0; i + 1 < DMAX; ++i)
             if (FULL || i + 1 < D) {
                 const T r = a - q[i];
-                s2 += r * r;
+                s2 = fma(r, r, s2);
             }
         return (s1 + s2) * inv_s + cst;
     }
     __device__ __forceinline__ void grad(const T (&q)[DMAX], T (&g)[DMAX]) const {
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) g[d] = T(0);
-#pragma unroll
-        for (int i = 0; i + 1 < DMAX; ++i)
-            if (FULL || i + 1 < D) {
-                const T t = q[i + 1] - q[i] * q[i];
-                g[i] += (((T(-4) * b) * q[i]) * t - T(2) * (a - q[i])) * inv_s;
-                g[i + 1] += ((T(2) * b) * t) * inv_s;
-            }
+        grad_each(q, [&](int d, T gd) { g[d] = gd; });
     }
-    // Same values as grad(), element by element: g_i = (0 + second_{i-1}) + first_i, where
-    // first_i = ((-4b q_i) t_i - 2(a - q_i))/s and second_i = (2b t_i)/s exist for i < D-1.
+    // g_i = (0 + c3*t_{i-1}) + fma(c1*q_i, t_i, -(c2*(a - q_i))), element by element
     template <typename F>
     __device__ __forceinline__ void grad_each(const T (&q)[DMAX], F&& visit) const {
-        T carry = T(0);  // second_{i-1}
+        T carry = T(0);
 #pragma unroll
         for (int i = 0; i < DMAX; ++i) {
             T gi = carry;
             carry = T(0);
             if (i + 1 < DMAX && (FULL || i + 1 < D)) {
-                const T t = q[i + 1] - q[i] * q[i];
-                gi += (((T(-4) * b) * q[i]) * t - T(2) * (a - q[i])) * inv_s;
-                carry = ((T(2) * b) * t) * inv_s;
+                const T t = fma(-q[i], q[i], q[i + 1]);
+                gi += fma(c1 * q[i], t, -(c2 * (a - q[i])));
+                carry = c3 * t;
             }
             visit(i, (FULL || i < D) ? gi : T(0));
         }
@@ -127,6 +122,10 @@ __device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T 
                                                 T (&v)[DMAX], T m, T h, int L) {
     const T h2 = h * h;
     const T half = T(0.5);
+    // (0.5*a)*h**2 == a*(0.5*h**2) and (0.5*(a+a'))*h == (a+a')*(0.5*h) bit for bit (scaling by
+    // 0.5 is exact), so the Leapfrog lines below cost 4 + 3 instead of 5 + 4 fp64 instructions
+    // and still reproduce src/integrator.py:112-117 exactly.
+    const T hh2 = half * h2, hh = half * h;
     T a[DMAX];
     if constexpr (UNIT) {
 #pragma unroll
@@ -141,10 +140,10 @@ __device__ __forceinline__ void integrate_chain(const Pot& pot, T (&q)[DMAX], T 
         pot.grad_each(q, [&](int d, T g) { a[d] = UNIT ? -g : -g / m; });
         for (int j = 0; j < L; ++j) {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + (half * a[d]) * h2);  // :112-115
+            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + a[d] * hh2);  // :112-115
             pot.grad_each(q, [&](int d, T g) {                                       // :116-118
                 const T an = UNIT ? -g : -g / m;
-                v[d] += (half * (a[d] + an)) * h;
+                v[d] += (a[d] + an) * hh;
                 a[d] = an;
             });
         }
@@ -394,7 +393,10 @@ SeparablePot<T, DMAX, FULL> make_sep(const pbbi_potential* pot) {
 }
 template <typename T, int DMAX, bool FULL>
 RosenbrockPot<T, DMAX, FULL> make_ros(const pbbi_potential* pot) {
-    return RosenbrockPot<T, DMAX, FULL>{(T)pot->a, (T)pot->b, (T)(1.0 / pot->s), (T)pot->cst, pot->D};
+    const double inv_s = 1.0 / pot->s;
+    return RosenbrockPot<T, DMAX, FULL>{(T)pot->a, (T)pot->b, (T)inv_s, (T)pot->cst,
+                                        (T)((-4.0 * pot->b) * inv_s), (T)(2.0 * inv_s),
+                                        (T)((2.0 * pot->b) * inv_s), pot->D};
 }
 
 inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + BLOCK - 1) / BLOCK)); }
@@ -542,6 +544,8 @@ int lane_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
+    static const bool no_lane2 = (getenv("PBBI_NO_LANE2") != nullptr);  // A/B switch
+    if (!no_lane2 && lane2_applies(a)) return lane2_hmc_iter(a);
     return launch_hmc<double>(a);
 }
 int lane_integrate(const IntegrateArgs& a) {

@@ -1,0 +1,253 @@
+// kernels_lane2.hip -- Rosenbrock potential, 16 < D <= 32, Leapfrog: TWO lanes per chain.
+//
+// BASELINE config 3 (Rosenbrock d = 32, 262 144 chains) is HBM-bound on paper (103 B and ~870
+// flop per step*chain), but with one chain per lane its q, v, a (192 VGPRs at D = 32) leave room
+// for only ONE wave per SIMD, so every wave's load, compute and store phases coincide and
+// nothing overlaps (measured: 22-28 % of the HBM roofline, time = memory time + VALU time).
+// Here lanes l and l^32 share a chain and hold 16 dims each (96 VGPRs of state): three waves
+// per SIMD fit, and one wave's HBM phase hides under the others' arithmetic.
+//
+//   lane l: chain c = l & 31 of the wave's 32 chains, half = l >> 5, dims i = 16*half + j.
+//   Loads/stores: each half-wave touches 32 consecutive chains of one row = 256 contiguous bytes.
+//   The only coupling across the halves is the nearest-neighbour term at i = 15/16: one
+//   v_permlane-style exchange of q_16 and one of the carried gradient term per evaluation.
+//
+// Arithmetic and summation ORDER are exactly the oracle's (and the chain-per-lane kernel's):
+// the sequential energy sums are continued across the halves (half 1 starts from half 0's
+// prefix), so q, p are bit-exact against the oracle, as for every chain-per-lane kernel.
+#include "pbbi_buf.h"
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+constexpr int BLOCK = 64;            // one wave = 32 chains per workgroup: 8192 small workgroups at
+constexpr int CHAINS_PER_BLOCK = 32; // C3 balance the last dispatch round better than 2048 of 4 waves
+constexpr int DL = 16;               // dims per lane
+
+struct Ros2Prm {
+    const double* q_in;
+    const double* p_in;
+    const double* u_in;
+    const double* mass;
+    double* q_out;
+    double* p_out;
+    double* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    double h, a, b, inv_s, cst, kT, c1, c2, c3;
+    int L, D, flags, rng;
+    uint64_t seed, iter, chain0;
+};
+
+__device__ __forceinline__ double xchg(double x) { return __shfl_xor(x, 32, 64); }
+
+// FULL: D == 32.  Then every dim exists and only the chain's last dim (half 1, j = 15) lacks a
+// right neighbour, so the per-lane predicates below fold to compile-time constants except for
+// one select -- without it they are divergent branches around every element.
+template <bool FULL>
+struct Ros2 {
+    double a, b, inv_s, cst, c1, c2, c3;  // c1 = (-4b)/s, c2 = 2/s, c3 = (2b)/s (see kernels_lane.hip)
+    int D, half;
+    // does global dim 16*half + j have a right neighbour inside D?
+    __device__ __forceinline__ bool has_next(int j) const {
+        if constexpr (FULL) return j + 1 < DL ? true : half == 0;
+        return 16 * half + j + 1 < D;
+    }
+    __device__ __forceinline__ bool exists(int j) const { return FULL ? true : 16 * half + j < D; }
+
+    // visit(j, g_j) for this lane's 16 dims; g_i = (0 + c3*t_{i-1}) + first_i (oracle order)
+    template <typename F>
+    __device__ __forceinline__ void grad_each(const double (&q)[DL], F&& visit) const {
+        const double q_ext = xchg(q[0]);  // half 0 receives q_16
+        // second_15 of half 0 feeds g_16 (local j = 0 of half 1)
+        const double t15 = fma(-q[15], q[15], q_ext);
+        const double sec15 = has_next(15) ? c3 * t15 : 0.0;
+        const double carry_ext = xchg(sec15);
+        double carry = half ? carry_ext : 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            const double t = fma(-q[j], q[j], qn);
+            const double first = fma(c1 * q[j], t, -(c2 * (a - q[j])));
+            const bool hn = has_next(j);
+            const double gj = hn ? carry + first : carry;  // select, not a branch
+            carry = hn ? c3 * t : 0.0;
+            visit(j, gj);
+        }
+    }
+
+    // U(q), valid in the half-1 lanes: the two sequential sums continue half 0's prefixes.
+    __device__ __forceinline__ double U(const double (&q)[DL]) const {
+        const double q_ext = xchg(q[0]);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {  // pass 0: from 0 (half 0's prefix); pass 1: continued
+            double r1 = pass ? xchg(s1) : 0.0, r2 = pass ? xchg(s2) : 0.0;
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+                const double t = fma(-q[j], q[j], qn);
+                const double n1 = fma(b * t, t, r1);
+                r1 = has_next(j) ? n1 : r1;
+            }
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const double r = a - q[j];
+                const double n2 = fma(r, r, r2);
+                r2 = has_next(j) ? n2 : r2;
+            }
+            if (pass == 0 || half) { s1 = r1; s2 = r2; }
+        }
+        return (s1 + s2) * inv_s + cst;
+    }
+};
+
+// sum_d p_d^2 in oracle order, valid in the half-1 lanes
+__device__ __forceinline__ double pp_seq(const double (&p)[DL], int half) {
+    double s = 0.0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        double r = pass ? xchg(s) : 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) r += p[j] * p[j];
+        if (pass == 0 || half) s = r;
+    }
+    return s;
+}
+
+template <bool UNIT, bool FULL>
+__global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, c = lane & 31;
+    const int64_t n0 = (int64_t)blockIdx.x * CHAINS_PER_BLOCK;  // block-uniform
+    const int cb = wave * 32 + c;                               // chain within the block
+    if (n0 + cb - c >= prm.N) return;                           // whole wave out of range
+    const int64_t left = prm.N - n0;
+    const bool valid = cb < left;
+    const int cc = valid ? cb : (int)left - 1;
+    const int D = prm.D;
+    const Ros2<FULL> pot{prm.a, prm.b, prm.inv_s, prm.cst, prm.c1, prm.c2, prm.c3, D, half};
+    const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
+    const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+    // buffer addressing: per-lane byte offset = column + this half's first row; row j via soffset
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vin = 8u * (uint32_t)cc + (uint32_t)(16 * half) * rin;
+    const uint32_t vout = 8u * (uint32_t)cc + (uint32_t)(16 * half) * rout;
+    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0);
+    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0);
+    auto exists = [&](int j) { return pot.exists(j); };
+
+    double q[DL], v[DL], a[DL];  // v holds p, then the velocity, then p again
+#pragma unroll
+    for (int j = 0; j < DL; ++j) q[j] = exists(j) ? buf_load<double>(bq, vin, (uint32_t)j * rin) : 0.0;
+    const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    auto draw = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // this half's group of 16 dims: blocks (half<<2)|r
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((half << 2) | r), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+        }
+    };
+    auto load_p = [&]() {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = exists(j) ? buf_load<double>(bp, vin, (uint32_t)j * rin) : 0.0;
+    };
+    if (prm.rng) draw(); else load_p();
+
+    // H(q_old, p_old), src/HMC.py:109-111; correct in the half-1 lanes, then shared with half 0
+    double oldH = 0.5 * pp_seq(v, half) / m + pot.U(q);
+    { const double o = xchg(oldH); if (!half) oldH = o; }
+
+    // ---- Leapfrog.integrate, src/integrator.py:105-120 (operation order kept)
+    // hh2, hh: bit-identical cheaper forms of (0.5*a)*h**2 and (0.5*(a+a'))*h (kernels_lane.hip)
+    const double h = prm.h, hh2 = 0.5 * (prm.h * prm.h), hh = 0.5 * prm.h;
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
+    }
+    pot.grad_each(q, [&](int j, double g) { a[j] = UNIT ? -g : -g / m; });
+    for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] += (v[j] * h + a[j] * hh2);
+        pot.grad_each(q, [&](int j, double g) {
+            const double an = UNIT ? -g : -g / m;
+            v[j] += (a[j] + an) * hh;
+            a[j] = an;
+        });
+    }
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+
+    double newH = 0.5 * pp_seq(v, half) / m + pot.U(q);
+    { const double o = xchg(newH); if (!half) newH = o; }
+    const double ratio = exp(oldH - newH);  // src/HMC.py:115
+    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j)
+            if (exists(j)) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < DL; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+                load_p();
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j)
+            if (exists(j)) buf_store(bqo, vout, (uint32_t)j * rout, q[j]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j)
+                if (exists(j)) buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
+        }
+        if (half == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + cb] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + cb] = reject ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace
+
+// true if this path takes the call (Rosenbrock, Leapfrog, fp64, 16 < D <= 32)
+bool lane2_applies(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    return pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 && a.method == PBBI_LEAPFROG &&
+           pot->D > 16 && pot->D <= 32;
+}
+
+int lane2_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (a.N == 0) return PBBI_OK;
+    Ros2Prm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+                (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
+                a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, 1.0 / pot->s, pot->cst,
+                a.kT, (-4.0 * pot->b) * (1.0 / pot->s), 2.0 * (1.0 / pot->s),
+                (2.0 * pot->b) * (1.0 / pot->s), a.L, pot->D, a.flags, a.rng, a.seed, a.iter,
+                a.chain0};
+    const dim3 grid((unsigned)((a.N + CHAINS_PER_BLOCK - 1) / CHAINS_PER_BLOCK)), block(BLOCK);
+    const bool full = (pot->D == 32);
+    if (a.mass) {
+        if (full) hipLaunchKernelGGL((k_ros2_hmc<false, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_ros2_hmc<false, false>), grid, block, 0, a.stream, prm);
+    } else {
+        if (full) hipLaunchKernelGGL((k_ros2_hmc<true, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_ros2_hmc<true, false>), grid, block, 0, a.stream, prm);
+    }
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}

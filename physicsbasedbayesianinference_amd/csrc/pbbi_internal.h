@@ -105,6 +105,9 @@ int lane_hmc_iter(const IterArgs& a);
 int lane_integrate(const IntegrateArgs& a);
 int lane_eval(const EvalArgs& a);
 int lane_energy(const EvalArgs& a);
+// Rosenbrock 16 < D <= 32, Leapfrog: two lanes per chain (config C3), kernels_lane2.hip
+bool lane2_applies(const IterArgs& a);
+int lane2_hmc_iter(const IterArgs& a);
 // dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
 int dense_hmc_iter(const IterArgs& a);
 int dense_integrate(const IntegrateArgs& a);

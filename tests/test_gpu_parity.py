@@ -612,3 +612,32 @@ def test_c5_shape_fp32_vs_fp64_oracle(P, lib):
     clear = np.abs(np.log(u) - np.minimum(0.0, np.log(ratio))) > 1e-2
     assert clear.sum() > N // 2
     assert np.array_equal(to_numpy(rj).astype(bool)[clear], rej[clear])
+
+
+# ------------------------------------------------------------------ two-lanes-per-chain Rosenbrock kernel
+@pytest.mark.parametrize("D,N,mass,compat", [(32, 1000, False, True), (32, 77, True, False),
+                                             (20, 130, True, True), (17, 33, False, True),
+                                             (31, 64, False, False)])
+def test_rosenbrock_two_lane_kernel_bitexact(P, lib, D, N, mass, compat):
+    """kernels_lane2.hip (16 < D <= 32, Leapfrog): bit-exact vs the oracle for full / padded D,
+    ragged N, non-unit masses, both momentum-restore conventions, with rejections present."""
+    rs = np.random.RandomState(D * 1000 + N)
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    q = 1.0 + 0.3 * rs.standard_normal((D, N))
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    h, L = 0.05, 10  # large enough step for rejections in the big case
+    n_rej = 0
+    for it in range(3):
+        p = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+        u = rs.uniform(size=N)
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, m, h, L, compat=compat)
+        q_or, p_or = q.copy(), p.copy()
+        r_or, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L,
+                                    compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(rej, rej_or)
+        assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
+        fin = np.isfinite(r_or) & (r_or > 0)
+        assert np.max(np.abs(np.log(ratio[fin]) - np.log(r_or[fin]))) < 1e-9
+        n_rej += int(rej.sum())
+        q = qo
+    assert n_rej > 0 or N < 1000

@@ -10,5 +10,5 @@ mkdir -p build/$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" \
     -c $C/kernels_dense.hip -o build/$name/kernels_dense.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/$name/libpbbi.so \
-    $C/pbbi_api.o $C/kernels_lane.o $C/kernels_big.o build/$name/kernels_dense.o
+    $C/pbbi_api.o $C/kernels_lane.o $C/kernels_lane2.o $C/kernels_big.o build/$name/kernels_dense.o
 echo build/$name/libpbbi.so
