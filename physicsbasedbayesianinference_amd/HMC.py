@@ -191,7 +191,7 @@ class HMC:
         synchronize(dev)
         self.reject_masks = to_numpy(reject).astype(bool)
         self.ratios = to_numpy(ratio)
-        self.acceptRate = 1.0 - float(self.reject_masks.mean()) if S > 0 else None
+        self.acceptRate = 1.0 - float(self.reject_masks.mean()) if S > 0 and N > 0 else None
         if S > 0:
             # leave the ensemble where the reference leaves it: q, p alias the final state
             if rng != "numpy":

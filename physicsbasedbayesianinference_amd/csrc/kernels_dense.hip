@@ -508,9 +508,18 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     STAMP(0);
     v2f64* frag2 = reinterpret_cast<v2f64*>(smem);
     double* mu = reinterpret_cast<double*>(smem + (size_t)DP * DP * sizeof(double));
-    {
+    {   // stage P: all 16-byte loads of a thread in flight at once (a rolled loop waits for each)
         const v2f64* src = reinterpret_cast<const v2f64*>(prm.frag);
-        for (int i = threadIdx.x; i < DP * DP / 2; i += BLOCK2) frag2[i] = src[i];
+        constexpr int NCH = DP * DP / 2 / BLOCK2;  // 16 at D = 128
+        if constexpr (NCH >= 1 && (DP * DP / 2) % BLOCK2 == 0) {
+            v2f64 tmp[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) tmp[j] = src[threadIdx.x + j * BLOCK2];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) frag2[threadIdx.x + j * BLOCK2] = tmp[j];
+        } else {
+            for (int i = threadIdx.x; i < DP * DP / 2; i += BLOCK2) frag2[i] = src[i];
+        }
         for (int i = threadIdx.x; i < DP; i += BLOCK2) mu[i] = prm.mu[i];
         __syncthreads();
     }
