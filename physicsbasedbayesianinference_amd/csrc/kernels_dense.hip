@@ -23,11 +23,12 @@
 //     that share a chain (every lane ends with identical bits -> uniform decision).
 //
 // Two kernels share these pieces:
-//   k_dense_hmc   production path, Leapfrog with L >= 1: two waves per SIMD, kick-drift-kick
-//                 state, row passes (see the comment above it; 76 % of the fp64 MFMA peak).
-//   k_dense_traj  general path: Stormer-Verlet, L = 0, and the reference's velocity-Verlet
-//                 operation order for Leapfrog (A/B switch PBBI_DENSE_V1): one wave per SIMD,
-//                 512-register budget, matrix pipe ~50 % busy.
+//   k_dense_hmc   production path, both integrators with L >= 1: two waves per SIMD,
+//                 kick-drift-kick state, row passes (see the comment above it; 0.86 of the fp64
+//                 MFMA peak on BASELINE config 2).
+//   k_dense_traj  general path: L = 0, and the reference's literal operation order for both
+//                 integrators (A/B switch PBBI_DENSE_V1): one wave per SIMD, 512-register budget,
+//                 matrix pipe ~50 % busy.
 //
 // Only the summation ORDER inside dot products (MFMA k-ordered fma chain, lane-group
 // butterfly) and, in k_dense_hmc, the algebraically equivalent kick-drift-kick update differ
@@ -496,7 +497,11 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 }
 
 // MODE 0: one HMC iteration (src/HMC.py:154-179).  MODE 1: integrate() in place.
-template <int NT, bool FULL, int MODE, bool ZMEAN>
+// METHOD: Leapfrog, or Stormer-Verlet (src/integrator.py:142-163), which in the same state is
+//   d = q_n - q_{n-1} = vh*h:  vh_1 = v_0 + (0.5*a_0)*h;  q_{n+1} = q_n + vh*h;  vh += a_n*h
+// i.e. kick-drift-kick WITHOUT the final half kick and with L+1 drifts; its returned velocity
+// (q_{L+1} - q_L)/h is vh itself.  U(q_new) then needs one more mat-vec at q_{L+1}.
+template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG>
 __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
@@ -602,8 +607,8 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     STAMP(4);
     xg = 0.0;
     for (int j = 0; j < prm.L; ++j) {
-        const bool last = (j == prm.L - 1);
-        const double cj = last ? ckh : ck;  // the last kick is a half kick
+        const bool last = (j == prm.L - 1) && METHOD == PBBI_LEAPFROG;
+        const double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
         STAMP(5 + 2 * j);
         matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, h);  // drift + g(q_{j+1})
         if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
@@ -615,7 +620,21 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
             kick_pass<NT, NTP, 1>(vh, acc, cj);
         }
     }
-    // vh = v_L, xg = x_L . g(q_L)
+    if constexpr (METHOD == PBBI_STORMER_VERLET) {
+        // position step L+1 (:155-159 on the last pass of the reference's loop)
+        if constexpr (MODE == 0) {  // drift inside the extra mat-vec that yields U(q_new)
+            matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, h);
+            xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+            if constexpr (NPASS == 2) {
+                matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+                xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) q[s] = fma(vh[s], h, q[s]);
+        }
+    }
+    // vh = final velocity, xg = x . g at the final position
 
     if constexpr (MODE == 1) {  // integrate(): in place q, p; optional Integrator.v
         const __amdgpu_buffer_rsrc_t vout_p = buf_make(prm.v_out + n0);
@@ -788,14 +807,22 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
     const dim3 grid(grid_size(pot, N)), block(BLOCK);
     const bool full = (pot->D == pot->DP);
     static const bool use_v1 = (getenv("PBBI_DENSE_V1") != nullptr);  // A/B switch for profiling
-    if (method == PBBI_LEAPFROG && prm.L >= 1 && !use_v1) {
+    if (prm.L >= 1 && !use_v1) {
         const int64_t tiles2 = (N + CHAINS_PER_WG2 - 1) / CHAINS_PER_WG2;
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
         const bool zmean = pot->zero_mean;
-#define LAUNCH3(NT_, F_, M_, Z_)                                                           \
-    {                                                                                      \
-        if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_>, lds)) return rc;                \
-        hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_>), grid2, block2, lds, stream, prm); \
+#define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
+    {                                                                                             \
+        if (method == PBBI_LEAPFROG) {                                                            \
+            if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>, lds)) return rc;    \
+            hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else {                                                                                  \
+            if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_STORMER_VERLET>, lds))         \
+                return rc;                                                                        \
+            hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_, PBBI_STORMER_VERLET>), grid2,        \
+                               block2, lds, stream, prm);                                         \
+        }                                                                                         \
     }
 #define CASE3F(NT_, F_)                                   \
     {                                                     \
