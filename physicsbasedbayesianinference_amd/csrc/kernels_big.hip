@@ -144,7 +144,7 @@ template <> struct MmaOf<float> { using type = MmaF32; };
 template <> struct MmaOf<double> { using type = MmaF64; };
 
 // ---- the GEMM with fused epilogue ----------------------------------------------------------------
-template <typename T, int EPI>
+template <typename T, int EPI, bool ZMEAN>
 __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
     constexpr int BK = Cfg<T>::BK;
     extern __shared__ __attribute__((aligned(16))) char smem_big[];
@@ -162,33 +162,56 @@ __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
     // staging map: 16-byte chunk c = tid + 256*j of a BK x 128 tile -> (k = c / CPR, x = VEC*(c % CPR)),
     // VEC elements per chunk, CPR = 128/VEC chunks per tile row: every wave instruction moves
     // whole 128-B..1-KiB row segments (coalesced), one global_load_dwordx4 per chunk.
+    // Every vector instruction costs matrix-pipe time (see kernels_dense.hip), so the common case
+    // -- whole tile inside D x N, aligned rows -- is a FAST path with loop-invariant 32-bit chunk
+    // offsets against a per-tile uniform base pointer and no selects; PMC showed 2.2 VALU
+    // instructions per MFMA with the guarded form.
     constexpr int VEC = 16 / sizeof(T);
     constexpr int CPR = BM / VEC;
     constexpr int NCH = BK * BM / VEC / NTHR;  // chunks per thread per tile (4)
     typedef T vecT __attribute__((ext_vector_type(VEC)));
-    // X rows may only be read 16 B at a time when the row stride keeps them aligned and the
-    // whole chunk is inside N; otherwise fall back to element loads for that chunk.
     const bool q_vec_ok = (prm.ldq % VEC == 0) && ((reinterpret_cast<uintptr_t>(prm.q) & 15) == 0);
+    const bool cols_full = q_vec_ok && (n0 + BN <= prm.N);          // block-uniform
+    uint32_t offA[NCH], offB[NCH];
+    int kc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = tid + NTHR * j, k = c / CPR, x = (c % CPR) * VEC;
+        kc[j] = k;
+        offA[j] = (uint32_t)k * (uint32_t)prm.DPAD + (uint32_t)x;
+        offB[j] = (uint32_t)k * (uint32_t)prm.ldq + (uint32_t)x;
+    }
+    const T* pa0 = prm.PT + i0;
+    const T* pb0 = prm.q + n0;
     vecT ra[NCH], rb[NCH];
     auto load_tiles = [&](int k0) {
+        const T* pa = pa0 + (size_t)k0 * prm.DPAD;  // uniform per tile
+        const T* pb = pb0 + (int64_t)k0 * prm.ldq;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = tid + NTHR * j, k = c / CPR, x = (c % CPR) * VEC;
-            ra[j] = *reinterpret_cast<const vecT*>(prm.PT + (size_t)(k0 + k) * prm.DPAD + i0 + x);
-            const int64_t n = n0 + x;
-            const int kr = k0 + k;
-            vecT v;
-            if (kr < prm.D && q_vec_ok && n + VEC <= prm.N) {
-                v = *reinterpret_cast<const vecT*>(prm.q + (int64_t)kr * prm.ldq + n);
-            } else {
+        for (int j = 0; j < NCH; ++j) ra[j] = *reinterpret_cast<const vecT*>(pa + offA[j]);
+        if (cols_full && k0 + BK <= prm.D) {  // fast path (uniform branch)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                vecT v = *reinterpret_cast<const vecT*>(pb + offB[j]);
+                if constexpr (!ZMEAN) {
+                    const T m = prm.mu[k0 + kc[j]];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] -= m;
+                }
+                rb[j] = v;
+            }
+        } else {  // edge tiles: element loads with zero fill
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int kr = k0 + kc[j];
+                const int64_t n = n0 + (int64_t)((tid + NTHR * j) % CPR) * VEC;
+                const T m = (!ZMEAN && kr < prm.D) ? prm.mu[kr] : T(0);
+                vecT v;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    v[e] = (kr < prm.D && n + e < prm.N) ? prm.q[(int64_t)kr * prm.ldq + n + e] : T(0);
+                    v[e] = (kr < prm.D && n + e < prm.N) ? prm.q[(int64_t)kr * prm.ldq + n + e] - m : T(0);
+                rb[j] = v;
             }
-            const T m = kr < prm.D ? prm.mu[kr] : T(0);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = (kr < prm.D && n + e < prm.N) ? v[e] - m : T(0);
-            rb[j] = v;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -226,7 +249,7 @@ __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
         const int64_t n = n0 + nl;
         if (i < prm.D && n < prm.N) {
             const T qv = prm.q[(int64_t)i * prm.ldq + n];
-            xg[tb] += (qv - prm.mu[i]) * g;
+            xg[tb] += (ZMEAN ? qv : qv - prm.mu[i]) * g;
             if constexpr (EPI == EPI_EVAL) {
                 if (prm.grad_out) prm.grad_out[(int64_t)i * prm.ldg + n] = g;
             } else {
@@ -414,15 +437,18 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
                    xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h};
     const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
     const size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
-    if (epi == EPI_EVAL) {
-        PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_gemm<T, EPI_EVAL>),
+    auto go = [&](auto kernel) -> int {
+        PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_big_gemm<T, EPI_EVAL>), dim3(tiles), dim3(NTHR), lds, st, prm);
-    } else {
-        PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_gemm<T, EPI_KDK>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_big_gemm<T, EPI_KDK>), dim3(tiles), dim3(NTHR), lds, st, prm);
-    }
+        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NTHR), lds, st, prm);
+        return PBBI_OK;
+    };
+    int rc;
+    if (epi == EPI_EVAL)
+        rc = pot->zero_mean ? go(k_big_gemm<T, EPI_EVAL, true>) : go(k_big_gemm<T, EPI_EVAL, false>);
+    else
+        rc = pot->zero_mean ? go(k_big_gemm<T, EPI_KDK, true>) : go(k_big_gemm<T, EPI_KDK, false>);
+    if (rc) return rc;
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
@@ -578,8 +604,10 @@ int big_build(pbbi_potential* pot, const double* P, const double* mean) {
             if (es == 8) ((double*)buf.data())[(size_t)k * DPAD + i] = v;
             else ((float*)buf.data())[(size_t)k * DPAD + i] = (float)v;
         }
+    pot->zero_mean = true;
     for (int d = 0; d < D; ++d) {
         const double v = mean ? mean[d] : 0.0;
+        if (v != 0.0) pot->zero_mean = false;
         if (es == 8) ((double*)mub.data())[d] = v;
         else ((float*)mub.data())[d] = (float)v;
     }
