@@ -641,3 +641,63 @@ def test_rosenbrock_two_lane_kernel_bitexact(P, lib, D, N, mass, compat):
         n_rej += int(rej.sum())
         q = qo
     assert n_rej > 0 or N < 1000
+
+
+# ------------------------------------------------------------------ more edge cases
+@pytest.mark.parametrize("D", [1, 3, 128, 130])
+@pytest.mark.parametrize("N", [0, 1, 17])
+def test_dense_tiny_shapes(P, D, N):
+    """Dense Gaussian at degenerate sizes (D = 1 pads to a 32-wide tile; D = 130 takes the GEMM path)."""
+    rs = np.random.RandomState(D + N)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    mu = rs.standard_normal(D)
+    pot, op = P.GaussianDense(mu, precision=Pm, const=0.0), orc.pot_gauss_dense(mu, Pm)
+    np.random.seed(3)
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, 0.5, 0.1, None, potential=pot, verbose=False)
+    s, m = hmc.getSamples(2, 1 / kB, 1.0)
+    assert s.shape == (D, N, 2)
+    if N:
+        ref = orc.get_samples_numpy_stream(op, "Leapfrog", D, N, 2, 0.5, 0.1, 1 / kB, 1.0, 3)
+        assert np.array_equal(hmc.reject_masks, ref["reject_mask"])
+        assert scaled_err(s, ref["samples"]) <= RTOL_DENSE and scaled_err(m, ref["momenta"]) <= RTOL_DENSE
+
+
+def test_hmc_run_without_optional_outputs(P, lib):
+    """momenta_out / reject_out / ratio_out are optional in pbbi_hmc_run; q_state carries over."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr
+    for pot, D in ((P.GaussianDense(None, precision=np.eye(40) * 2.0, const=0.0), 40), (P.Rosenbrock(32), 32),
+                   (P.StandardGaussian(5), 5)):
+        N, S = 200, 3
+        q = torch.full((D, N), 0.9, dtype=torch.float64, device="cuda")
+        q2 = q.clone()
+        s1 = empty((S, D, N), np.float64, 0)
+        s2, m2 = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        r2 = empty((S, N), np.uint8, 0)
+        lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, s1.data_ptr(), None, None, None,
+                 N, N, 0.01, 5, S, 1, 3, 0, 0, 1.0, stream_ptr(0))
+        lib.call("pbbi_hmc_run", pot.handle, 0, q2.data_ptr(), None, s2.data_ptr(), m2.data_ptr(),
+                 r2.data_ptr(), None, N, N, 0.01, 5, S, 1, 3, 0, 0, 1.0, stream_ptr(0))
+        torch.cuda.synchronize()
+        assert torch.equal(s1, s2) and torch.equal(q, q2) and torch.equal(q, s1[S - 1])
+
+
+def test_padded_leading_stride(P, lib):
+    """ldn > N: kernels honour the leading stride of the (D, N) layout."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import stream_ptr
+    for pot in (P.GaussianDense(None, precision=np.eye(16) + 0.1, const=0.0), P.Harmonic(np.arange(1, 7.0))):
+        D, N, ld = pot.numDimensions, 50, 64
+        g = torch.Generator(device="cuda").manual_seed(0)
+        qp = torch.randn((D, ld), dtype=torch.float64, device="cuda", generator=g)
+        pp = torch.randn((D, ld), dtype=torch.float64, device="cuda", generator=g)
+        qc, pc = qp[:, :N].contiguous(), pp[:, :N].contiguous()
+        pad_q = qp[:, N:].clone()
+        lib.call("pbbi_leapfrog", pot.handle, qp.data_ptr(), pp.data_ptr(), None, N, ld, 0.1, 7, stream_ptr(0))
+        lib.call("pbbi_leapfrog", pot.handle, qc.data_ptr(), pc.data_ptr(), None, N, N, 0.1, 7, stream_ptr(0))
+        torch.cuda.synchronize()
+        assert torch.equal(qp[:, :N], qc) and torch.equal(pp[:, :N], pc)
+        assert torch.equal(qp[:, N:], pad_q)  # padding columns untouched
