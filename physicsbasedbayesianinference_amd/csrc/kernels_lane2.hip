@@ -56,24 +56,28 @@ struct Ros2 {
     }
     __device__ __forceinline__ bool exists(int j) const { return FULL ? true : 16 * half + j < D; }
 
-    // visit(j, g_j) for this lane's 16 dims; g_i = (0 + c3*t_{i-1}) + first_i (oracle order)
+    // visit(j, -g_j) for this lane's 16 dims.  The oracle's g_i = (0 + c3*t_{i-1}) + first_i is
+    // produced NEGATED (what getAccel needs): every term is negated exactly -- -c1, -c3 and the
+    // swapped sign inside the fma -- so -g is bit-identical to negating the oracle's g, without
+    // one sign-flip instruction per element.
     template <typename F>
-    __device__ __forceinline__ void grad_each(const double (&q)[DL], F&& visit) const {
+    __device__ __forceinline__ void neg_grad_each(const double (&q)[DL], F&& visit) const {
         const double q_ext = xchg(q[0]);  // half 0 receives q_16
-        // second_15 of half 0 feeds g_16 (local j = 0 of half 1)
+        const double nc1 = -c1, nc3 = -c3;
+        // -second_15 of half 0 feeds -g_16 (local j = 0 of half 1)
         const double t15 = fma(-q[15], q[15], q_ext);
-        const double sec15 = has_next(15) ? c3 * t15 : 0.0;
-        const double carry_ext = xchg(sec15);
+        const double nsec15 = has_next(15) ? nc3 * t15 : 0.0;
+        const double carry_ext = xchg(nsec15);
         double carry = half ? carry_ext : 0.0;
 #pragma unroll
         for (int j = 0; j < DL; ++j) {
             const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
             const double t = fma(-q[j], q[j], qn);
-            const double first = fma(c1 * q[j], t, -(c2 * (a - q[j])));
+            const double nfirst = fma(nc1 * q[j], t, c2 * (a - q[j]));
             const bool hn = has_next(j);
-            const double gj = hn ? carry + first : carry;  // select, not a branch
-            carry = hn ? c3 * t : 0.0;
-            visit(j, gj);
+            const double ngj = hn ? carry + nfirst : carry;  // select, not a branch
+            carry = hn ? nc3 * t : 0.0;
+            visit(j, ngj);
         }
     }
 
@@ -170,12 +174,12 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    pot.grad_each(q, [&](int j, double g) { a[j] = UNIT ? -g : -g / m; });
+    pot.neg_grad_each(q, [&](int j, double ng) { a[j] = UNIT ? ng : ng / m; });
     for (int s = 0; s < prm.L; ++s) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) q[j] += (v[j] * h + a[j] * hh2);
-        pot.grad_each(q, [&](int j, double g) {
-            const double an = UNIT ? -g : -g / m;
+        pot.neg_grad_each(q, [&](int j, double ng) {
+            const double an = UNIT ? ng : ng / m;
             v[j] += (a[j] + an) * hh;
             a[j] = an;
         });
