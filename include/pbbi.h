@@ -190,6 +190,14 @@ int pbbi_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N
 int pbbi_transpose_sdn_to_dns(const void* src_sdn, void* dst_dns, int S, int D, int64_t N,
                               int dtype, int device, void* stream);
 
+/* ---- streaming statistics (the sample sink) -----------------------
+ * Per-dimension mean and (biased) variance over all S*N draws of (S, D, N) device slabs,
+ * without moving the samples off the GPU: mean_out[d], var_out[d] (D elements each, dtype of
+ * the slabs; accumulated in fp64, two deterministic stages, no atomics).  The reference only
+ * returns the (D, N, S) array (src/HMC.py:136-183); at C2 scale that is 6.7 GB per 100 draws. */
+int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                        void* mean_out, void* var_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

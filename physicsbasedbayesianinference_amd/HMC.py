@@ -203,6 +203,21 @@ class HMC:
             return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
         return self._to_dns(samples), self._to_dns(momenta)
 
+    def sampleMoments(self, samples_dns):
+        """Per-dimension (mean, variance) over every draw of every chain, computed on the GPU from
+        the (D, N, S) device view that getSamples(device_output=True) returns -- the sample sink
+        for runs whose (D, N, S) array is too large to pull to the host."""
+        pot = self._pot
+        sdn = samples_dns.permute(2, 0, 1)  # back to the (S, D, N) slabs (a view)
+        if not sdn.is_contiguous():
+            sdn = sdn.contiguous()
+        S, D, N = sdn.shape
+        mean = empty((D,), pot.dtype, pot.device)
+        var = empty((D,), pot.dtype, pot.device)
+        _lib.call("pbbi_sample_moments", sdn.data_ptr(), S, D, N, pot._dt, pot.device,
+                  mean.data_ptr(), var.data_ptr(), stream_ptr(pot.device))
+        return to_numpy(mean).astype(np.float64), to_numpy(var).astype(np.float64)
+
     def _to_dns(self, sdn):
         """(S, D, N) device slabs -> host (D, N, S) array via the LDS-tiled transpose kernel."""
         pot = self._pot

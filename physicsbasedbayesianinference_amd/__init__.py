@@ -12,11 +12,11 @@ Modules mirror the reference's `src/` files: ensemble, integrator, potential, HM
 """
 from .ensemble import Ensemble
 from .potential import (GaussianDense, GaussianDiag, Harmonic, Potential, Rosenbrock,
-                        StandardGaussian, harmonicPotentialND)
+                        StandardGaussian, harmonicPotentialND, linear_regression_posterior)
 from .integrator import Integrator, Leapfrog, StormerVerlet
 from .HMC import HMC
 
 __all__ = ["Ensemble", "HMC", "Integrator", "Leapfrog", "StormerVerlet", "Potential",
            "Harmonic", "GaussianDiag", "StandardGaussian", "GaussianDense", "Rosenbrock",
-           "harmonicPotentialND"]
+           "harmonicPotentialND", "linear_regression_posterior"]
 __version__ = "0.1.0"

@@ -125,6 +125,53 @@ __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int 
     }
 }
 
+// moments stage 1: block (d, chunk) sums x and x^2 over its slice of the S*N draws of row d
+template <typename T>
+__global__ void k_moments_partial(const T* __restrict__ x, int S, int D, int64_t N, int chunks,
+                                  double* __restrict__ part /* [D][chunks][2] */) {
+    const int d = blockIdx.y, ch = blockIdx.x;
+    const int64_t total = (int64_t)S * N;
+    const int64_t per = (total + chunks - 1) / chunks;
+    const int64_t lo = (int64_t)ch * per, hi = lo + per < total ? lo + per : total;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int64_t sidx = i / N, n = i - sidx * N;
+        const double v = (double)x[(sidx * D + d) * N + n];
+        s1 += v;
+        s2 += v * v;
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            r1[threadIdx.x] += r1[threadIdx.x + w];
+            r2[threadIdx.x] += r2[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[((size_t)d * chunks + ch) * 2 + 0] = r1[0];
+        part[((size_t)d * chunks + ch) * 2 + 1] = r2[0];
+    }
+}
+
+template <typename T>
+__global__ void k_moments_final(const double* __restrict__ part, int D, int chunks, double count,
+                                T* mean_out, T* var_out) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        s1 += part[((size_t)d * chunks + c) * 2 + 0];
+        s2 += part[((size_t)d * chunks + c) * 2 + 1];
+    }
+    const double mean = s1 / count;
+    if (mean_out) mean_out[d] = (T)mean;
+    if (var_out) var_out[d] = (T)(s2 / count - mean * mean);
+}
+
 }  // namespace
 
 // ======================================================================= library
@@ -392,6 +439,35 @@ int pbbi_transpose_sdn_to_dns(const void* src_sdn, void* dst_dns, int S, int D, 
     else
         return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
     PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// =================================================================== statistics
+int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                        void* mean_out, void* var_out, void* stream) {
+    if (S < 1 || D < 1 || N < 1) return pbbi_fail(PBBI_ERR_INVALID, "S, D, N must be >= 1");
+    if (!samples_sdn) return pbbi_fail(PBBI_ERR_INVALID, "samples is NULL");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    DeviceGuard guard(device);
+    const int chunks = 64;
+    double* part = nullptr;
+    PBBI_HIP(hipMallocAsync((void**)&part, (size_t)D * chunks * 2 * sizeof(double), (hipStream_t)stream));
+    const dim3 grid(chunks, D), block(256);
+    if (dtype == PBBI_F64) {
+        hipLaunchKernelGGL(k_moments_partial<double>, grid, block, 0, (hipStream_t)stream,
+                           (const double*)samples_sdn, S, D, N, chunks, part);
+        hipLaunchKernelGGL(k_moments_final<double>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                           (const double*)part, D, chunks, (double)S * (double)N, (double*)mean_out,
+                           (double*)var_out);
+    } else {
+        hipLaunchKernelGGL(k_moments_partial<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float*)samples_sdn, S, D, N, chunks, part);
+        hipLaunchKernelGGL(k_moments_final<float>, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                           (const double*)part, D, chunks, (double)S * (double)N, (float*)mean_out,
+                           (float*)var_out);
+    }
+    PBBI_HIP(hipGetLastError());
+    PBBI_HIP(hipFreeAsync(part, (hipStream_t)stream));
     return PBBI_OK;
 }
 

@@ -27,7 +27,7 @@ from . import _lib
 from ._device import as_device, default_device, empty, stream_ptr, to_numpy, torch_dtype
 
 __all__ = ["Potential", "Harmonic", "GaussianDiag", "StandardGaussian", "GaussianDense",
-           "Rosenbrock", "harmonicPotentialND", "noPotential"]
+           "Rosenbrock", "harmonicPotentialND", "noPotential", "linear_regression_posterior"]
 
 
 def _dptr(arr):
@@ -182,6 +182,26 @@ class GaussianDense(Potential):
         self.mean, self.precision, self.const = mean, P, float(const)
         _lib.call("pbbi_potential_create_gauss_dense", D, _dptr(mean), _dptr(P), self.const,
                   self._dt, self.device, C.byref(self._handle))
+
+
+def linear_regression_posterior(X, y, noise_var, prior_precision=0.0, prior_mean=None, **kw):
+    """Model -> potential for the conjugate Bayesian linear model (the
+    free-fall regression of the reference's notes): y = X w + eps, eps ~ N(0, noise_var),
+    w ~ N(prior_mean, prior_precision^-1).  The posterior is Gaussian, so its potential
+    -log p(w | X, y) is a GaussianDense descriptor with
+        P = X^T X / noise_var + Lambda,   mean = P^-1 (X^T y / noise_var + Lambda prior_mean)
+    (constant dropped).  Parameter set-up on the host; sampling runs on the dense kernels."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).ravel()
+    M, D = X.shape
+    if y.size != M:
+        raise ValueError("X has %d rows, y has %d entries" % (M, y.size))
+    Lam = np.asarray(prior_precision, dtype=np.float64)
+    Lam = np.eye(D) * Lam if Lam.ndim == 0 else (np.diag(Lam) if Lam.ndim == 1 else Lam)
+    m0 = np.zeros(D) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64).ravel()
+    P = X.T @ X / noise_var + Lam
+    mean = np.linalg.solve(P, X.T @ y / noise_var + Lam @ m0)
+    return GaussianDense(mean, precision=P, const=0.0, **kw)
 
 
 class Rosenbrock(Potential):

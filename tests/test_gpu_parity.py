@@ -701,3 +701,28 @@ def test_padded_leading_stride(P, lib):
         torch.cuda.synchronize()
         assert torch.equal(qp[:, :N], qc) and torch.equal(pp[:, :N], pc)
         assert torch.equal(qp[:, N:], pad_q)  # padding columns untouched
+
+
+# ------------------------------------------------------------------ SURVEY 8f rows 1 and 4
+def test_linear_regression_posterior_sampling_and_moments(P):
+    """Model -> potential for Bayesian linear regression, sampled with the ensemble kernels, with
+    the moments taken by the on-device sample sink: posterior mean and marginal variances are
+    recovered (statistical check) and the moments kernel equals NumPy on the same draws."""
+    rs = np.random.RandomState(0)
+    M, D, N, S = 200, 6, 4096, 100
+    X = rs.standard_normal((M, D))
+    w_true = rs.standard_normal(D)
+    y = X @ w_true + 0.5 * rs.standard_normal(M)
+    pot = P.linear_regression_posterior(X, y, noise_var=0.25, prior_precision=1.0)
+    Sigma = np.linalg.inv(pot.precision)
+    ens = P.Ensemble(D, N)
+    # omega*T in (1.4, 2.0) for every eigen-direction of P: away from the k*pi resonances
+    hmc = P.HMC(ens, 0.06, 0.006, None, potential=pot, rng="philox", seed=1, verbose=False)
+    s_dev, _ = hmc.getSamples(S, 1 / kB, 1.0, device_output=True)
+    mean, var = hmc.sampleMoments(s_dev[:, :, 50:])          # discard burn-in draws
+    draws = s_dev[:, :, 50:].cpu().numpy()
+    assert np.allclose(mean, draws.mean(axis=(1, 2)), rtol=0, atol=1e-12)
+    assert np.allclose(var, draws.var(axis=(1, 2)), rtol=1e-10, atol=1e-14)
+    assert np.max(np.abs(mean - pot.mean)) < 0.005
+    assert np.max(np.abs(var / np.diag(Sigma) - 1.0)) < 0.1
+    assert hmc.acceptRate > 0.9
