@@ -137,6 +137,54 @@ def main_c3(args):
                      "launch_ms": ks * 1e3}}))
 
 
+def main_stream(args):
+    """Extra: the workspace-streaming chain-per-lane kernels (kernels_stream.hip): Rosenbrock at
+    D > 64 or in fp32.  Reports the rate, the algorithmic-bytes roofline fraction (samples in/out
+    only, as for C3) and the rate of the kernel's own design traffic (q, v, a read and written
+    once per element-step)."""
+    import torch
+    import physicsbasedbayesianinference_amd as P
+    from physicsbasedbayesianinference_amd import _lib
+    d, N, h, L = args.dim, args.chains, 0.01, 10
+    f32 = args.dtype == "f32"
+    tdt, w, code = (torch.float32, 4, _lib.F32) if f32 else (torch.float64, 8, _lib.F64)
+    K, W = args.steps, args.warmup
+    pot = P.Rosenbrock(d, dtype="float32" if f32 else "float64")
+    stream = torch.cuda.current_stream().cuda_stream
+    q = torch.empty((d, N), dtype=tdt, device="cuda")
+    _lib.call("pbbi_philox_normal", 7, _lib.STREAM_POSITION, 0, 0, d, N, N, 0.1, None, code, 0,
+              q.data_ptr(), stream)
+    q += 1.0
+    S_alloc = max(K, W, 1)
+    samples = torch.empty((S_alloc, d, N), dtype=tdt, device="cuda")
+    momenta = torch.empty((S_alloc, d, N), dtype=tdt, device="cuda")
+    reject = torch.empty((S_alloc, N), dtype=torch.uint8, device="cuda")
+
+    def run(S, it0):
+        _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
+                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, 1, 7, it0, 0, 1.0, stream)
+    run(W, 0)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(); run(K, W); ev1.record()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    ks = ev0.elapsed_time(ev1) * 1e-3 / K
+    bytes_launch = bytes_per_step_chain(d, L, w) * L * N
+    design = (6 * L + 12) * w * d * N  # per launch: 6 accesses per element-step + init/energy/output sweeps
+    print(json.dumps({
+        "metric": f"leapfrog-steps*chains/sec; Rosenbrock d={d}, ensemble={N}, {args.dtype} (streaming path)",
+        "value": K * L * N / t, "unit": "leapfrog-steps*chains/s", "n_gpus": 1, "steps": K,
+        "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"Rosenbrock d={d}, {N} chains, L=10, h=0.01",
+                   "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
+        "roofline": {"bound": "hbm", "kernel": "k_stream_hmc",
+                     "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "design_traffic_GBs": design / ks / 1e9, "launch_ms": ks * 1e3}}))
+
+
 def main_c5(args):
     """BASELINE config 5: d=4096 dense-precision Gaussian, 8192 chains, fp32, h=0.05, L=10:
     L+1 fused MFMA GEMMs per HMC iteration (kernels_big.hip).  MFMA-bound."""
@@ -186,12 +234,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chains", type=int, default=N_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "stream"],
                     help="c2 (default, the BASELINE metric) or c3 (Rosenbrock d=32, 262144 chains: "
                          "the HBM-bound chain-per-lane kernel; extra, not the headline line)")
+    ap.add_argument("--dim", type=int, default=128, help="--workload stream: dimension")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
     args = ap.parse_args()
     if args.workload == "c3":
         return main_c3(args)
+    if args.workload == "stream":
+        return main_stream(args)
     if args.workload == "c5":
         return main_c5(args)
 

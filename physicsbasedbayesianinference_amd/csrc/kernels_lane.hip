@@ -528,20 +528,13 @@ int check_ld(const pbbi_potential* pot, int64_t ld) {
     return PBBI_OK;
 }
 
-int check(const pbbi_potential* pot) {
-    if (pot->dtype != PBBI_F64)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "chain-per-lane kernels are built for fp64 only");
-    if (pick_dmax(pot->D) == 0)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
-                         "chain-per-lane kernels hold D <= 64 in registers; D = " +
-                             std::to_string(pot->D) + " is not supported for this potential yet");
-    return PBBI_OK;
-}
+// D > 64 or fp32: the chain's state lives in a device workspace (kernels_stream.hip)
+inline bool streams(const pbbi_potential* pot) { return pot->dtype != PBBI_F64 || pick_dmax(pot->D) == 0; }
 
 }  // namespace
 
 int lane_hmc_iter(const IterArgs& a) {
-    if (int rc = check(a.pot)) return rc;
+    if (streams(a.pot)) return stream_hmc_iter(a);
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
     static const bool no_lane2 = (getenv("PBBI_NO_LANE2") != nullptr);  // A/B switch
@@ -549,19 +542,19 @@ int lane_hmc_iter(const IterArgs& a) {
     return launch_hmc<double>(a);
 }
 int lane_integrate(const IntegrateArgs& a) {
-    if (int rc = check(a.pot)) return rc;
+    if (streams(a.pot)) return stream_integrate(a);
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     return launch_integrate<double>(a);
 }
 int lane_eval(const EvalArgs& a) {
-    if (int rc = check(a.pot)) return rc;
+    if (streams(a.pot)) return stream_eval(a);
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     return launch_eval<double>(a, 0);
 }
 int lane_energy(const EvalArgs& a) {
-    if (int rc = check(a.pot)) return rc;
+    if (streams(a.pot)) return stream_energy(a);
     if (int rc = check_ld(a.pot, a.ldn)) return rc;
     if (a.N == 0) return PBBI_OK;
     const int mode = a.ratio_finish ? 2 : 1;

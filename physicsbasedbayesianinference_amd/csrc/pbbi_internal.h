@@ -108,6 +108,11 @@ int lane_energy(const EvalArgs& a);
 // Rosenbrock 16 < D <= 32, Leapfrog: two lanes per chain (config C3), kernels_lane2.hip
 bool lane2_applies(const IterArgs& a);
 int lane2_hmc_iter(const IterArgs& a);
+// the same potentials for D > 64 and for fp32: chain state in a device workspace, kernels_stream.hip
+int stream_hmc_iter(const IterArgs& a);
+int stream_integrate(const IntegrateArgs& a);
+int stream_eval(const EvalArgs& a);
+int stream_energy(const EvalArgs& a);
 // dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
 int dense_hmc_iter(const IterArgs& a);
 int dense_integrate(const IntegrateArgs& a);

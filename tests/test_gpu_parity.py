@@ -426,9 +426,9 @@ def test_error_behaviour(P, lib):
         P.Integrator(ens, 0.1, 1.0, pot.gradient).integrate()           # src/integrator.py:87-91
     with pytest.raises(IndexError):
         ens.particle(5)                                                 # src/ensemble.py:102-107
-    big = P.Harmonic(np.ones(65))  # chain-per-lane kernels hold D <= 64
-    with pytest.raises(lib.PbbiError):
-        big(np.zeros(65))
+    big = P.GaussianDense(None, precision=np.eye(130))
+    with pytest.raises(lib.PbbiError):                                  # D > 128 dense: Leapfrog only
+        P.StormerVerlet(P.Ensemble(130, 4), 0.1, 1.0, big).integrate()
 
 
 # ------------------------------------------------------------------ sharded API / properties
@@ -726,3 +726,89 @@ def test_linear_regression_posterior_sampling_and_moments(P):
     assert np.max(np.abs(mean - pot.mean)) < 0.005
     assert np.max(np.abs(var / np.diag(Sigma) - 1.0)) < 0.1
     assert hmc.acceptRate > 0.9
+
+
+# ------------------------------------------------------------------ D > 64 / fp32 chain-per-lane
+def _stream_case(P, kind, D, rs, dtype="float64"):
+    if kind == "harmonic":
+        k = rs.uniform(0.5, 2.0, D)
+        return P.Harmonic(k, dtype=dtype), orc.pot_harmonic(k)
+    if kind == "diag":
+        mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2.0, D)
+        return P.GaussianDiag(mu, prec=prec, const=0.25, dtype=dtype), orc.pot_gauss_diag(mu, prec, 0.25)
+    return P.Rosenbrock(D, dtype=dtype), orc.pot_rosenbrock(D)
+
+
+@pytest.mark.parametrize("kind,D,N,method,mass", [
+    ("harmonic", 65, 100, "Leapfrog", False), ("diag", 100, 130, "Stormer-Verlet", True),
+    ("diag", 72, 64, "Leapfrog", True), ("rosenbrock", 70, 200, "Leapfrog", False),
+    ("rosenbrock", 128, 65, "Stormer-Verlet", False), ("rosenbrock", 257, 70, "Leapfrog", True)])
+def test_streaming_lane_path_bit_exact(P, lib, kind, D, N, method, mass):
+    """D > 64: the chain's q, v, a live in a device workspace (kernels_stream.hip); same
+    arithmetic in the same order as the oracle => bit-identical q, p, masks, energies."""
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D)
+    pot, op = _stream_case(P, kind, D, rs)
+    L, h = 7, (0.02 if kind == "rosenbrock" else 0.9)
+    q = rs.standard_normal((D, N)) * (0.3 if kind == "rosenbrock" else 1.0)
+    p = rs.standard_normal((D, N))
+    u = rs.uniform(size=N)
+    u[::3] = 1.5  # u > min(1, ratio) whatever the ratio: every third chain takes the reject branch
+    m = (1.0 + (np.arange(N) % 4) * 0.5) if mass else None
+    if mass:
+        p *= np.sqrt(m)
+    for compat in (True, False):
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, m, h, L, compat=compat)
+        q_or, p_or = q.copy(), p.copy()
+        r_or, rej_or = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L,
+                                      compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(rej, rej_or)
+        assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
+        assert np.max(np.abs(np.log(ratio) - np.log(r_or))) < 1e-8
+    assert 0 < rej.sum() < N
+    # potential / gradient / integrate through the class API
+    U, g = pot.value_and_gradient(q)
+    U_or, g_or = orc.potential(op, q, want_grad=True)
+    assert np.array_equal(U, U_or) and np.array_equal(g, g_or)
+    ens = P.Ensemble(D, N)
+    ens.q, ens.p = q.copy(), p.copy()
+    if mass:
+        ens.mass = m.copy()
+    cls = P.Leapfrog if method == "Leapfrog" else P.StormerVerlet
+    qi, pi = cls(ens, h, L * h + 1e-9, pot).integrate()
+    q2, p2 = q.copy(), p.copy()
+    orc.integrate(op, method, q2, p2, m, h, L)
+    assert np.array_equal(qi, q2) and np.array_equal(pi, p2)
+
+
+def test_streaming_lane_path_philox_and_fp32(P, lib):
+    """In-kernel draws on the streaming path (oracle replay from the device draws, bit-exact),
+    and the fp32 build of the same kernels against the fp64 oracle (single-precision tolerance)."""
+    D, N, S, L, h = 96, 150, 3, 5, 0.01
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    ens = P.Ensemble(D, N)
+    seed, chain0, iter0 = 11, 5, 2
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=chain0, iter0=iter0)
+    q = device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 0.3)
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, iter0 + i, chain0, D, N, 1.0, np.ones(N))
+        u = device_uniform(lib, seed, iter0 + i, chain0, N)
+        _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, None, h, L)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert np.array_equal(samples[:, :, i], q) and np.array_equal(momenta[:, :, i], p)
+    # fp32: D = 32 (lane kernels are fp64-only, so this runs the streaming kernels) and D = 80
+    for D32 in (32, 80):
+        rs = np.random.RandomState(D32)
+        pot32, op = _stream_case(P, "diag", D32, rs, dtype="float32")
+        q = rs.standard_normal((D32, N)).astype(np.float32).astype(np.float64)
+        p = rs.standard_normal((D32, N)).astype(np.float32).astype(np.float64)
+        ens = P.Ensemble(D32, N)
+        ens.q, ens.p = q.copy(), p.copy()
+        qi, pi = P.Leapfrog(ens, 0.1, 1.0 + 1e-6, pot32).integrate()
+        q2, p2 = q.copy(), p.copy()
+        orc.integrate(op, "Leapfrog", q2, p2, None, 0.1, 10)
+        assert scaled_err(qi, q2) <= 2e-5 and scaled_err(pi, p2) <= 2e-5
+        U, g = pot32.value_and_gradient(q)
+        U_or, g_or = orc.potential(op, q, want_grad=True)
+        assert scaled_err(U, U_or) <= 1e-5 and scaled_err(g, g_or) <= 1e-5
