@@ -24,7 +24,8 @@
 //     that X panel (K x 128) stays hot while it is reused D/128 times; P^T (64 MiB at D=4096
 //     fp32) is re-read by every X panel and stays resident in the 256 MiB Infinity Cache.
 //
-// Leapfrog only; Stormer-Verlet and D > 128 fails loudly (PBBI_ERR_UNSUPPORTED).
+// Stormer-Verlet runs on the same epilogue: no closing half kick, one more drift, and one
+// evaluation GEMM for U of the final position.
 #include <vector>
 
 #include "pbbi_internal.h"
@@ -487,26 +488,43 @@ int run_hmc(const IterArgs& a) {
     hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)pdraw,
                        (int64_t)N, D, N, SQ_ROWS, pp_old);
     const T h = (T)a.h, hh = (T)(0.5 * a.h);
-    // L + 1 GEMMs; q_0 is the caller's q_in, then ping-pong between qa and qb
+    // Leapfrog: L + 1 GEMMs (half kick, L-1 kicks, half kick; L drifts).  Stormer-Verlet
+    // (src/integrator.py:142-163) is the same recurrence without the closing half kick and with one
+    // more drift -- d = q_n - q_{n-1} = vh*h -- so every GEMM kicks and drifts (L + 1 of each), the
+    // final velocity is vh, and U of the final position takes one more (evaluation) GEMM.
+    // q_0 is the caller's q_in, then ping-pong between qa and qb.
+    const bool sv = (a.method == PBBI_STORMER_VERLET);
     const T* qcur = (const T*)a.q_in;
     int64_t ldcur = a.ldn_in;
-    for (int j = 0; j <= L; ++j) {
-        const bool first = (j == 0), last = (j == L);
-        T* qnext = last ? nullptr : ((j & 1) ? qb : qa);
-        if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0,
-                             first ? xg_old : (last ? xg_new : nullptr), N,
-                             (first || last) ? hh : h, h, st))
+    const T* xg_fin = xg_new;
+    if (!sv && L == 0) {  // nothing moves: one evaluation serves both Hamiltonians
+        if (int rc = gemm<T>(pot, EPI_EVAL, qcur, ldcur, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                             xg_old, N, T(0), T(0), st))
             return rc;
-        if (L == 0) break;  // single evaluation: q does not move, xg_new = xg_old
-        if (!last) { qcur = qnext; ldcur = N; }
+        xg_fin = xg_old;
+        hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, qcur, ldcur, qa, (int64_t)N, D, N,
+                           T(1), (const T*)nullptr);  // the select kernel reads stride-N workspaces
+        qcur = qa;
+    } else {
+        for (int j = 0; j <= L; ++j) {
+            const bool first = (j == 0), last = (j == L), drift = sv || !last;
+            T* qnext = drift ? ((j & 1) ? qb : qa) : nullptr;
+            if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0,
+                                 first ? xg_old : ((last && !sv) ? xg_new : nullptr), N,
+                                 (first || (last && !sv)) ? hh : h, h, st))
+                return rc;
+            if (drift) { qcur = qnext; ldcur = N; }
+        }
+        if (sv)
+            if (int rc = gemm<T>(pot, EPI_EVAL, qcur, ldcur, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                                 xg_new, N, T(0), T(0), st))
+                return rc;
     }
-    // NOTE: with L == 0 the "first" epilogue applied a half kick; the reference leaves p untouched.
-    // L == 0 is rejected by the caller (big_hmc_iter) for this path.
     hipLaunchKernelGGL(k_big_v_to_p<T>, grid2d(N, D), b1, 0, st, vh, (int64_t)N, D, N, (const T*)a.mass);
     hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)vh,
                        (int64_t)N, D, N, SQ_ROWS, pp_new);
     hipLaunchKernelGGL(k_big_decide<T>, g1, b1, 0, st, (const T*)pp_old, (const T*)pp_new, n_sq,
-                       (const T*)xg_old, (const T*)xg_new, n_xg, (const T*)a.mass, (const T*)a.u_in,
+                       (const T*)xg_old, xg_fin, n_xg, (const T*)a.mass, (const T*)a.u_in,
                        a.rng, a.seed, a.iter, a.chain0, (T)pot->cst, N, (T*)a.ratio_out, rej);
     hipLaunchKernelGGL(k_big_select<T>, grid2d(N, D), b1, 0, st, (const T*)a.q_in, a.ldn_in, qcur,
                        (const T*)vh, (const T*)pdraw, (int64_t)N, (const uint8_t*)rej,
@@ -538,13 +556,14 @@ int run_integrate(const IntegrateArgs& a) {
     const T h = (T)a.h, hh = (T)(0.5 * a.h);
     const T* qcur = (const T*)a.q;
     int64_t ldcur = a.ldn;
-    for (int j = 0; j <= L && L > 0; ++j) {
-        const bool first = (j == 0), last = (j == L);
-        T* qnext = last ? nullptr : ((j & 1) ? qb : qa);
+    const bool sv = (a.method == PBBI_STORMER_VERLET);
+    for (int j = 0; j <= L && (sv || L > 0); ++j) {
+        const bool first = (j == 0), last = (j == L), drift = sv || !last;
+        T* qnext = drift ? ((j & 1) ? qb : qa) : nullptr;
         if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0, nullptr, N,
-                             (first || last) ? hh : h, h, st))
+                             (first || (last && !sv)) ? hh : h, h, st))
             return rc;
-        if (!last) { qcur = qnext; ldcur = N; }
+        if (drift) { qcur = qnext; ldcur = N; }
     }
     if (a.v_out)
         hipLaunchKernelGGL(k_big_copy<T>, grid2d(N, D), b1, 0, st, (const T*)vh, (int64_t)N,
@@ -620,18 +639,12 @@ int big_build(pbbi_potential* pot, const double* P, const double* mean) {
 
 int big_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
-    if (a.method != PBBI_LEAPFROG)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: Leapfrog only in this build");
-    if (a.L < 1)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: numSteps must be >= 1");
     if (a.N == 0) return PBBI_OK;
     return a.pot->dtype == PBBI_F64 ? run_hmc<double>(a) : run_hmc<float>(a);
 }
 
 int big_integrate(const IntegrateArgs& a) {
     if (int rc = check(a.pot)) return rc;
-    if (a.method != PBBI_LEAPFROG)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "dense Gaussian with D > 128: Leapfrog only in this build");
     if (a.N == 0) return PBBI_OK;
     return a.pot->dtype == PBBI_F64 ? run_integrate<double>(a) : run_integrate<float>(a);
 }

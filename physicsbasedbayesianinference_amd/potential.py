@@ -154,7 +154,7 @@ class GaussianDense(Potential):
     0.5*(P + P^T).  With `const=None` the constant is 0.5*log det(2 pi cov), i.e.
     U = -multivariate_normal.logpdf(q, mean, cov) as in src/tests/test_HMC.py:49,125.
     D <= 128 in float64 runs on the register-resident MFMA kernels; larger D (and float32)
-    on the streaming MFMA-GEMM path (one fused GEMM per leapfrog step; Leapfrog only).
+    on the streaming MFMA-GEMM path (one fused GEMM per integrator step).
     """
 
     kind = "gauss_dense"

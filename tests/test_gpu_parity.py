@@ -426,9 +426,8 @@ def test_error_behaviour(P, lib):
         P.Integrator(ens, 0.1, 1.0, pot.gradient).integrate()           # src/integrator.py:87-91
     with pytest.raises(IndexError):
         ens.particle(5)                                                 # src/ensemble.py:102-107
-    big = P.GaussianDense(None, precision=np.eye(130))
-    with pytest.raises(lib.PbbiError):                                  # D > 128 dense: Leapfrog only
-        P.StormerVerlet(P.Ensemble(130, 4), 0.1, 1.0, big).integrate()
+    with pytest.raises(ValueError):                                     # D mismatch
+        P.Leapfrog(P.Ensemble(3, 4), 0.1, 1.0, pot).integrate()
 
 
 # ------------------------------------------------------------------ sharded API / properties
@@ -537,8 +536,11 @@ def test_big_dense_asymmetric_matrix_layout(P):
     assert scaled_err(pot.gradient(q), M @ q) <= 1e-13
 
 
-@pytest.mark.parametrize("D,mass", [(192, False), (300, True)])
-def test_big_dense_integrate_vs_oracle(P, D, mass):
+@pytest.mark.parametrize("D,mass,method,L", [(192, False, "Leapfrog", 10), (300, True, "Leapfrog", 10),
+                                             (192, True, "Stormer-Verlet", 10),
+                                             (260, False, "Stormer-Verlet", 0),
+                                             (200, True, "Leapfrog", 0)])
+def test_big_dense_integrate_vs_oracle(P, D, mass, method, L):
     Pm, mu = _dense_problem(D, 3)
     N = 90
     pot = P.GaussianDense(mu, precision=Pm, const=0.0)
@@ -550,13 +552,34 @@ def test_big_dense_integrate_vs_oracle(P, D, mass):
     ens.q[...] = rs.standard_normal((D, N))
     ens.p[...] = rs.standard_normal((D, N))
     qo, po = ens.q.copy(), ens.p.copy()
-    integ = P.Leapfrog(ens, 0.1, 1.0, pot)
+    cls = P.Leapfrog if method == "Leapfrog" else P.StormerVerlet
+    integ = cls(ens, 0.1, 0.1 * L + 1e-9, pot)
+    assert integ.numSteps == L
     q, p = integ.integrate()
-    vo = orc.integrate(orc.pot_gauss_dense(mu, Pm), "Leapfrog", qo, po, m, 0.1, 10)
+    vo = orc.integrate(orc.pot_gauss_dense(mu, Pm), method, qo, po, m, 0.1, L)
     assert scaled_err(q, qo) <= RTOL_DENSE and scaled_err(p, po) <= RTOL_DENSE
     assert scaled_err(integ.v, vo) <= RTOL_DENSE
-    with pytest.raises(Exception):  # Stormer-Verlet is not built for D > 128: fails loudly
-        P.StormerVerlet(ens, 0.1, 1.0, pot).integrate()
+
+
+@pytest.mark.parametrize("method,L", [("Stormer-Verlet", 6), ("Stormer-Verlet", 0), ("Leapfrog", 0)])
+def test_big_dense_hmc_iter_methods_vs_oracle(P, lib, method, L):
+    """D > 128: Stormer-Verlet and the zero-step trajectory on the GEMM path (padded input stride
+    is covered by gpu_hmc_iter's contiguous arrays; masks equal, state within the dense tolerance)."""
+    D, N, h = 200, 150, 0.3
+    Pm, mu = _dense_problem(D, 8)
+    pot, op = P.GaussianDense(mu, precision=Pm, const=0.0), orc.pot_gauss_dense(mu, Pm)
+    rs = np.random.RandomState(9)
+    q, p, u = rs.standard_normal((D, N)), rs.standard_normal((D, N)), rs.uniform(size=N)
+    m = 1.0 + (np.arange(N) % 3) * 0.5
+    p *= np.sqrt(m)
+    qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, m, h, L)
+    q_or, p_or = q.copy(), p.copy()
+    r_or, rej_or = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L)
+    assert np.array_equal(rej, rej_or)
+    assert scaled_err(qo, q_or) <= RTOL_DENSE and scaled_err(po, p_or) <= RTOL_DENSE
+    assert np.max(np.abs(np.log(ratio) - np.log(r_or))) < 1e-8
+    if L:
+        assert 0 < rej.sum() < N
 
 
 @pytest.mark.parametrize("rng", ["numpy", "philox"])
