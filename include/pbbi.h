@@ -109,6 +109,15 @@ int pbbi_potential_create_gauss_dense(int D, const double* mean, const double* p
                                       double cst, int dtype, int device, pbbi_potential** out);
 int pbbi_potential_create_rosenbrock(int D, double a, double b, double s, int dtype, int device,
                                      pbbi_potential** out);
+/* User-defined potential -- the counterpart of the reference's arbitrary Python callables
+ * (`potential=` / `gradient=` of src/HMC.py:35-60, src/integrator.py:36-59).  The two functions
+ * are stated in C++ (contract in physicsbasedbayesianinference_amd/custom.py and
+ * csrc/pbbi_custom.h), compiled by hipcc for gfx950 into a plugin shared object whose kernels
+ * have them inlined; `plugin_path` names that file.  `params` (host, float64, may be NULL when
+ * n_params == 0) is copied to the device in the handle's dtype and passed to both functions:
+ * model constants, or the data set of a Bayesian model. */
+int pbbi_potential_create_custom(const char* plugin_path, int D, const double* params, int n_params,
+                                 int dtype, int device, pbbi_potential** out);
 int pbbi_potential_destroy(pbbi_potential* pot);
 int pbbi_potential_dim(const pbbi_potential* pot);
 int pbbi_potential_dtype(const pbbi_potential* pot);

@@ -30,7 +30,7 @@
 
 #define ORACLE_MAXD 8192
 
-enum { POT_HARMONIC = 0, POT_GAUSS_DIAG = 1, POT_GAUSS_DENSE = 2, POT_ROSENBROCK = 3 };
+enum { POT_HARMONIC = 0, POT_GAUSS_DIAG = 1, POT_GAUSS_DENSE = 2, POT_ROSENBROCK = 3, POT_CUSTOM = 4 };
 enum { METHOD_LEAPFROG = 0, METHOD_STORMER_VERLET = 1 };
 /* compat flag bit 0: reproduce src/HMC.py:176 (rejected momentum <- oldQ) */
 enum { COMPAT_P_FROM_OLDQ = 1 };
@@ -43,6 +43,12 @@ typedef struct {
                            dense: D x D row-major precision matrix           */
     double cst;         /* additive constant of U                            */
     double a, b, s;     /* Rosenbrock parameters                             */
+    /* POT_CUSTOM: the user's potential / gradient source (the one the product compiles into its
+     * HIP kernels, physicsbasedbayesianinference_amd/custom.py) compiled for the host by
+     * oracle.py::pot_custom; `prec` carries its parameter array.  Stands for the reference's
+     * arbitrary callables (src/HMC.py:52-60, src/integrator.py:73).                          */
+    double (*user_U)(const double* q, int D, const double* prm);
+    void (*user_grad)(const double* q, double* g, int D, const double* prm);
 } oracle_pot;
 
 int oracle_version(void) { return 1; }
@@ -108,6 +114,8 @@ static double pot_U(const oracle_pot* P, const double* q) {
         }
         return (s1 + s2) * inv_s + P->cst;
     }
+    case POT_CUSTOM:
+        return P->user_U(q, D, P->prec);
     }
     return NAN;
 }
@@ -145,6 +153,9 @@ static void pot_grad(const oracle_pot* P, const double* q, double* g) {
         }
         return;
     }
+    case POT_CUSTOM:
+        P->user_grad(q, g, D, P->prec);
+        return;
     }
 }
 

@@ -15,8 +15,9 @@ from .potential import (GaussianDense, GaussianDiag, Harmonic, Potential, Rosenb
                         StandardGaussian, harmonicPotentialND, linear_regression_posterior)
 from .integrator import Integrator, Leapfrog, StormerVerlet
 from .HMC import HMC
+from .custom import CustomPotential
 
 __all__ = ["Ensemble", "HMC", "Integrator", "Leapfrog", "StormerVerlet", "Potential",
            "Harmonic", "GaussianDiag", "StandardGaussian", "GaussianDense", "Rosenbrock",
-           "harmonicPotentialND", "linear_regression_posterior"]
+           "harmonicPotentialND", "linear_regression_posterior", "CustomPotential"]
 __version__ = "0.1.0"

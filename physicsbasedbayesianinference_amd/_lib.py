@@ -42,6 +42,7 @@ PROTOTYPES = {
     "pbbi_potential_create_gauss_diag": [_i, _dp, _dp, _d, _i, _i, _pp],
     "pbbi_potential_create_gauss_dense": [_i, _dp, _dp, _d, _i, _i, _pp],
     "pbbi_potential_create_rosenbrock": [_i, _d, _d, _d, _i, _i, _pp],
+    "pbbi_potential_create_custom": [C.c_char_p, _i, _dp, _i, _i, _i, _pp],
     "pbbi_potential_destroy": [_vp],
     "pbbi_potential_dim": [_vp],
     "pbbi_potential_dtype": [_vp],

@@ -1,6 +1,8 @@
 // pbbi_api.hip -- the extern "C" surface declared in include/pbbi.h: handle management,
 // argument checking and dispatch to the kernel translation units.  No arithmetic of the
 // hot path lives here and nothing falls back to the host.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -54,6 +56,9 @@ int new_handle(int kind, int D, int dtype, int device, pbbi_potential** out) {
     p->d_mean = p->d_prec = p->d_frag = p->d_mean_pad = p->d_big_PT = p->d_big_mu = nullptr;
     p->DP = 0;
     p->DPAD_big = 0;
+    p->plugin = p->d_params = nullptr;
+    p->n_params = 0;
+    p->plugin_hmc_iter = nullptr; p->plugin_integrate = nullptr; p->plugin_eval = nullptr;
     p->zero_mean = true;
     *out = p;
     return PBBI_OK;
@@ -87,6 +92,35 @@ inline bool is_dense(const pbbi_potential* pot) {  // register-resident MFMA pat
 }
 inline bool is_big(const pbbi_potential* pot) {  // streaming GEMM path
     return pot->kind == KIND_GAUSS_DENSE && pot->DP == 0;
+}
+
+// ---- routing: which kernel family serves a handle -----------------------------------------------
+int plugin_rc(int rc) {
+    if (rc == 0) return PBBI_OK;
+    if (rc < 0) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the chain workspace");
+    return pbbi_fail(PBBI_ERR_HIP, std::string("user-potential kernel launch: ") +
+                                       hipGetErrorString((hipError_t)rc));
+}
+int route_hmc(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
+    return route_hmc(a);
+}
+int route_integrate(const IntegrateArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_integrate(&a)) : PBBI_OK;
+    return route_integrate(a);
+}
+int route_eval(const EvalArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_eval(&a, 0)) : PBBI_OK;
+    return route_eval(a);
+}
+int route_energy(const EvalArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->kind == KIND_CUSTOM)
+        return a.N ? plugin_rc(pot->plugin_eval(&a, a.ratio_finish ? 2 : 1)) : PBBI_OK;
+    return route_energy(a);
 }
 
 // ---- small utility kernels ---------------------------------------------------
@@ -246,11 +280,48 @@ int pbbi_potential_create_rosenbrock(int D, double a, double b, double s, int dt
     return PBBI_OK;
 }
 
+int pbbi_potential_create_custom(const char* plugin_path, int D, const double* params, int n_params,
+                                 int dtype, int device, pbbi_potential** out) {
+    if (!plugin_path) return pbbi_fail(PBBI_ERR_INVALID, "plugin_path is NULL");
+    if (n_params < 0 || (n_params > 0 && !params))
+        return pbbi_fail(PBBI_ERR_INVALID, "params is NULL / n_params < 0");
+    if (int rc = new_handle(KIND_CUSTOM, D, dtype, device, out)) return rc;
+    pbbi_potential* p = *out;
+    DeviceGuard guard(device);
+    p->plugin = dlopen(plugin_path, RTLD_NOW | RTLD_LOCAL);
+    if (!p->plugin) {
+        const char* why = dlerror();
+        return finish_or_destroy(pbbi_fail(PBBI_ERR_INVALID, std::string("cannot load the potential plugin: ") +
+                                                                 (why ? why : plugin_path)), out);
+    }
+    auto abi = (int (*)(void))dlsym(p->plugin, "pbbi_plugin_abi");
+    auto pdt = (int (*)(void))dlsym(p->plugin, "pbbi_plugin_dtype");
+    p->plugin_hmc_iter = (int (*)(const IterArgs*))dlsym(p->plugin, "pbbi_plugin_hmc_iter");
+    p->plugin_integrate = (int (*)(const IntegrateArgs*))dlsym(p->plugin, "pbbi_plugin_integrate");
+    p->plugin_eval = (int (*)(const EvalArgs*, int))dlsym(p->plugin, "pbbi_plugin_eval");
+    int rc = PBBI_OK;
+    if (!abi || !pdt || !p->plugin_hmc_iter || !p->plugin_integrate || !p->plugin_eval)
+        rc = pbbi_fail(PBBI_ERR_INVALID, "plugin does not export the pbbi_plugin_* entry points");
+    else if (abi() != PBBI_PLUGIN_ABI)
+        rc = pbbi_fail(PBBI_ERR_INVALID, "plugin was built against another libpbbi (ABI " +
+                                             std::to_string(abi()) + ", expected " +
+                                             std::to_string(PBBI_PLUGIN_ABI) + "): rebuild it");
+    else if (pdt() != dtype)
+        rc = pbbi_fail(PBBI_ERR_INVALID, "plugin was built for the other dtype");
+    if (rc == PBBI_OK) {
+        p->n_params = n_params;
+        rc = upload(params, (size_t)n_params, dtype, &p->d_params);
+    }
+    return finish_or_destroy(rc, out);
+}
+
 int pbbi_potential_destroy(pbbi_potential* pot) {
     if (!pot) return PBBI_OK;
     DeviceGuard guard(pot->device);
-    for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad, pot->d_big_PT, pot->d_big_mu})
+    for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad, pot->d_big_PT, pot->d_big_mu,
+                    pot->d_params})
         if (p) (void)hipFree(p);
+    if (pot->plugin) (void)dlclose(pot->plugin);
     delete pot;
     return PBBI_OK;
 }
@@ -265,7 +336,7 @@ int pbbi_potential_eval(const pbbi_potential* pot, const void* q, int64_t N, int
     if (!q && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q is NULL");
     DeviceGuard guard(pot->device);
     EvalArgs a{pot, q, nullptr, nullptr, N, ldn, U_out, grad_out, nullptr, 0, (hipStream_t)stream};
-    return is_big(pot) ? big_eval(a) : is_dense(pot) ? dense_eval(a) : lane_eval(a);
+    return route_eval(a);
 }
 
 // ==================================================================== integrators
@@ -278,7 +349,7 @@ int pbbi_integrate(const pbbi_potential* pot, int method, void* q, void* p, cons
     if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
     DeviceGuard guard(pot->device);
     IntegrateArgs a{pot, method, q, p, mass, v_out, N, ldn, h, L, (hipStream_t)stream};
-    return is_big(pot) ? big_integrate(a) : is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
+    return route_integrate(a);
 }
 
 int pbbi_leapfrog(const pbbi_potential* pot, void* q, void* p, const void* mass, int64_t N,
@@ -298,7 +369,7 @@ int pbbi_energy(const pbbi_potential* pot, const void* q, const void* p, const v
     if ((!q || !p) && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "q / p is NULL");
     DeviceGuard guard(pot->device);
     EvalArgs a{pot, q, p, mass, N, ldn, H_out, nullptr, weight_out, 0, (hipStream_t)stream};
-    return is_big(pot) ? big_energy(a) : is_dense(pot) ? dense_energy(a) : lane_energy(a);
+    return route_energy(a);
 }
 
 int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* newP,
@@ -311,9 +382,9 @@ int pbbi_weights_ratio(const pbbi_potential* pot, const void* newQ, const void* 
     DeviceGuard guard(pot->device);
     // pass 1: ratio_out <- oldH ; pass 2: ratio_out <- exp(ratio_out - newH)   (src/HMC.py:109-115)
     EvalArgs a{pot, oldQ, oldP, mass, N, ldn, ratio_out, nullptr, nullptr, 0, (hipStream_t)stream};
-    if (int rc = is_big(pot) ? big_energy(a) : is_dense(pot) ? dense_energy(a) : lane_energy(a)) return rc;
+    if (int rc = route_energy(a)) return rc;
     EvalArgs b{pot, newQ, newP, mass, N, ldn, ratio_out, nullptr, nullptr, 1, (hipStream_t)stream};
-    return is_big(pot) ? big_energy(b) : is_dense(pot) ? dense_energy(b) : lane_energy(b);
+    return route_energy(b);
 }
 
 // ================================================================ HMC iteration(s)
@@ -338,7 +409,7 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
     a.q_out = q_out; a.p_out = p_out; a.ratio_out = ratio_out; a.reject_out = reject_out;
     a.N = N; a.ldn_in = ldn; a.ldn_out = ldn; a.h = h; a.L = L; a.flags = flags;
     a.rng = 0; a.kT = 1.0; a.stream = (hipStream_t)stream;
-    return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
+    return route_hmc(a);
 }
 
 int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
@@ -368,8 +439,7 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         a.N = N; a.h = h; a.L = L; a.flags = flags;
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = (hipStream_t)stream;
-        if (int rc = is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a))
-            return rc;
+        if (int rc = route_hmc(a)) return rc;
     }
     // leave the chain state in q_state (strided D2D copy of the last slab)
     PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * es,

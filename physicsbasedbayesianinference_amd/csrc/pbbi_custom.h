@@ -1,0 +1,445 @@
+// pbbi_custom.h -- the ensemble-HMC kernels of a USER-DEFINED potential, gfx950.
+//
+// The reference accepts any Python callable as potential / gradient (src/HMC.py:52-60,
+// src/integrator.py:73).  A GPU kernel cannot call Python, so the user states the two functions
+// in C++ (custom.py documents the contract); custom.py generates a translation unit
+//
+//     #include "pbbi_internal.h" / "pbbi_rng.h"
+//     using T = double;  (or float)            #define PBBI_FN __device__ __forceinline__
+//     namespace user { <the user's source> }
+//     #include "pbbi_custom.h"
+//
+// and hipcc builds it into a plugin .so that libpbbi.so loads (pbbi_potential_create_custom).
+// The user's functions are inlined into the kernels below -- no indirect calls on the device.
+//
+//     template <class Q>          PBBI_FN T    potential(const Q& q, int D, const T* prm);
+//     template <class Q, class G> PBBI_FN void gradient (const Q& q, G& g, int D, const T* prm);
+//
+// q[j] reads and g[j] = ... writes element j of ONE chain (both are strided views of (D, N)
+// arrays, chain index fastest, so a wave's accesses are 512-byte contiguous).
+//
+// One chain per lane; q, v, a and the gradient live in a (D, N) device workspace.  Operation
+// order is the reference's (src/integrator.py:105-120, 142-163; src/HMC.py:100-115, 164-179),
+// the same as kernels_stream.hip; the oracle restates it around the same user source compiled
+// for the host (oracle/oracle.py::pot_custom).
+#pragma once
+#include <vector>
+
+namespace pbbi_custom {
+
+constexpr int SB = 64;  // chains per workgroup (one wave)
+constexpr int CH = 8;   // rows per batch of loads
+
+template <class E>
+struct Col {  // element j of one chain's column of a (D, N) array
+    E* base;
+    int64_t ld;
+    __device__ __forceinline__ E& operator[](int j) const { return base[(int64_t)j * ld]; }
+};
+
+template <int CNT>
+__device__ __forceinline__ void load_rows(const T* col, int64_t ld, int j0, int D, T (&x)[CNT]) {
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        const int j = j0 + k < D ? j0 + k : D - 1;  // clamped: no branch, always a valid address
+        x[k] = col[(int64_t)j * ld];
+    }
+}
+
+template <typename F>
+__device__ __forceinline__ void draw_rows(uint64_t seed, uint64_t iter, uint64_t chain, int D,
+                                          double pstd, F&& visit) {
+    for (int G = 0; 16 * G < D; ++G) {
+        float z[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), z[r]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int d = 16 * G + k;
+            if (d < D) visit(d, (T)((double)z[k & 3][k >> 2] * pstd));
+        }
+    }
+}
+
+struct Chain {  // one chain's columns of the workspaces
+    T *q, *v, *a, *g;
+    int64_t ld;
+    int D;
+    const T* prm;
+    __device__ __forceinline__ T potential() const {
+        return user::potential(Col<const T>{q, ld}, D, prm);
+    }
+    __device__ __forceinline__ void gradient() const {
+        Col<T> gg{g, ld};
+        user::gradient(Col<const T>{q, ld}, gg, D, prm);
+    }
+};
+
+// after gradient(): Leapfrog a0 = -g/m (:108); Stormer-Verlet qpast = q0 (kept in a),
+// q1 = (q0 + v h) + (0.5 a0) h^2 (:147-150)
+template <int METHOD, bool UNIT>
+__device__ __forceinline__ void first_sweep(const Chain& c, T m, T h) {
+    const T h2 = h * h, half = T(0.5);
+    for (int j0 = 0; j0 < c.D; j0 += CH) {
+        T g[CH], q[CH], v[CH];
+        load_rows<CH>(c.g, c.ld, j0, c.D, g);
+        if constexpr (METHOD == PBBI_STORMER_VERLET) {
+            load_rows<CH>(c.q, c.ld, j0, c.D, q);
+            load_rows<CH>(c.v, c.ld, j0, c.D, v);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = j0 + k;
+            if (j < c.D) {
+                const T a = UNIT ? -g[k] : -g[k] / m;  // src/integrator.py:73
+                if constexpr (METHOD == PBBI_LEAPFROG) {
+                    c.a[(int64_t)j * c.ld] = a;
+                } else {
+                    c.a[(int64_t)j * c.ld] = q[k];
+                    c.q[(int64_t)j * c.ld] = (q[k] + v[k] * h) + (half * a) * h2;
+                }
+            }
+        }
+    }
+}
+
+template <int METHOD, bool UNIT>
+__device__ __forceinline__ void trajectory(const Chain& c, T m, T h, int L) {
+    const T h2 = h * h, hh = T(0.5) * h, hh2 = T(0.5) * h2;
+    c.gradient();
+    first_sweep<METHOD, UNIT>(c, m, h);
+    for (int s = 0; s < L; ++s) {
+        if constexpr (METHOD == PBBI_LEAPFROG) {
+            for (int j0 = 0; j0 < c.D; j0 += CH) {  // q += v h + a (0.5 h^2)   (:112-115)
+                T q[CH], v[CH], a[CH];
+                load_rows<CH>(c.q, c.ld, j0, c.D, q);
+                load_rows<CH>(c.v, c.ld, j0, c.D, v);
+                load_rows<CH>(c.a, c.ld, j0, c.D, a);
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (j0 + k < c.D) c.q[(int64_t)(j0 + k) * c.ld] = q[k] + (v[k] * h + a[k] * hh2);
+            }
+            c.gradient();
+            for (int j0 = 0; j0 < c.D; j0 += CH) {  // v += (a + a') (0.5 h); a = a'   (:116-118)
+                T g[CH], v[CH], a[CH];
+                load_rows<CH>(c.g, c.ld, j0, c.D, g);
+                load_rows<CH>(c.v, c.ld, j0, c.D, v);
+                load_rows<CH>(c.a, c.ld, j0, c.D, a);
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (j0 + k < c.D) {
+                        const T an = UNIT ? -g[k] : -g[k] / m;
+                        c.v[(int64_t)(j0 + k) * c.ld] = v[k] + (a[k] + an) * hh;
+                        c.a[(int64_t)(j0 + k) * c.ld] = an;
+                    }
+            }
+        } else {
+            c.gradient();
+            for (int j0 = 0; j0 < c.D; j0 += CH) {  // q' = (2 q - qpast) + a h^2   (:152-158)
+                T g[CH], q[CH], qp[CH];
+                load_rows<CH>(c.g, c.ld, j0, c.D, g);
+                load_rows<CH>(c.q, c.ld, j0, c.D, q);
+                load_rows<CH>(c.a, c.ld, j0, c.D, qp);
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (j0 + k < c.D) {
+                        const T a = UNIT ? -g[k] : -g[k] / m;
+                        c.q[(int64_t)(j0 + k) * c.ld] = (T(2) * q[k] - qp[k]) + a * h2;
+                        c.a[(int64_t)(j0 + k) * c.ld] = q[k];
+                    }
+            }
+        }
+    }
+}
+
+template <int METHOD>
+__device__ __forceinline__ T final_v(T q, T v_or_qpast, T h) {
+    if constexpr (METHOD == PBBI_STORMER_VERLET) return (q - v_or_qpast) / h;  // :160
+    else return v_or_qpast;
+}
+
+struct HmcPrm {
+    const T* q_in;
+    const T* p_in;
+    const T* u_in;
+    const T* mass;
+    T* q_out;
+    T* p_out;
+    T* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    T h;
+    int L, D, flags, rng;
+    uint64_t seed, iter, chain0;
+    double kT;
+    const T* prm;
+    T *Wq, *Wv, *Wa, *Wg;
+};
+
+template <int METHOD, bool UNIT>
+__global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
+    const int64_t n = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const int64_t ld = prm.N;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    const uint64_t chain = prm.chain0 + (uint64_t)n;
+    const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
+    const Chain c{prm.Wq + n, prm.Wv + n, prm.Wa + n, prm.Wg + n, ld, D, prm.prm};
+    const T* qin = prm.q_in + n;
+    const T* pin = prm.rng ? nullptr : prm.p_in + n;
+
+    T pp = T(0), u;
+    if (prm.rng) {
+        draw_rows(prm.seed, prm.iter, chain, D, pstd, [&](int d, T p) {
+            pp += p * p;
+            c.v[(int64_t)d * ld] = UNIT ? p : p / m;
+        });
+        u = (T)rng_uniform(prm.seed, prm.iter, chain);
+    } else {
+        for (int j0 = 0; j0 < D; j0 += CH) {
+            T p[CH];
+            load_rows<CH>(pin, prm.ldn_in, j0, D, p);
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (j0 + k < D) {
+                    pp += p[k] * p[k];
+                    c.v[(int64_t)(j0 + k) * ld] = UNIT ? p[k] : p[k] / m;
+                }
+        }
+        u = prm.u_in[n];
+    }
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T q[CH];
+        load_rows<CH>(qin, prm.ldn_in, j0, D, q);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (j0 + k < D) c.q[(int64_t)(j0 + k) * ld] = q[k];
+    }
+    const T oldH = T(0.5) * pp / m + c.potential();  // src/HMC.py:100-102
+    trajectory<METHOD, UNIT>(c, m, prm.h, prm.L);
+    T pp1 = T(0);
+    const T* vsrc = METHOD == PBBI_STORMER_VERLET ? c.a : c.v;
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T q[CH], v[CH];
+        load_rows<CH>(c.q, ld, j0, D, q);
+        load_rows<CH>(vsrc, ld, j0, D, v);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (j0 + k < D) {
+                const T vj = final_v<METHOD>(q[k], v[k], prm.h);
+                const T p = UNIT ? vj : vj * m;
+                pp1 += p * p;
+            }
+    }
+    const T newH = T(0.5) * pp1 / m + c.potential();
+    const T ratio = exp(oldH - newH);  // src/HMC.py:115
+    // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
+    const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+
+    T* qo = prm.q_out + n;
+    T* po = prm.p_out ? prm.p_out + n : nullptr;
+    const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T q[CH], v[CH], qi[CH];
+        load_rows<CH>(c.q, ld, j0, D, q);
+        load_rows<CH>(vsrc, ld, j0, D, v);
+        load_rows<CH>(qin, prm.ldn_in, j0, D, qi);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = j0 + k;
+            if (j < D) {
+                qo[(int64_t)j * prm.ldn_out] = reject ? qi[k] : q[k];  // :175
+                if (po) {
+                    const T vj = final_v<METHOD>(q[k], v[k], prm.h);
+                    T pj = UNIT ? vj : vj * m;
+                    if (reject) pj = compat ? qi[k] : (pin ? pin[(int64_t)j * prm.ldn_in] : T(0));
+                    po[(int64_t)j * prm.ldn_out] = pj;  // :176 (compat: p <- oldQ)
+                }
+            }
+        }
+    }
+    if (po && reject && !compat && prm.rng)
+        draw_rows(prm.seed, prm.iter, chain, D, pstd,
+                  [&](int d, T p) { po[(int64_t)d * prm.ldn_out] = p; });
+    if (prm.ratio_out) prm.ratio_out[n] = ratio;
+    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+}
+
+struct IntPrm {
+    T* q;
+    T* p;
+    const T* mass;
+    T* v_out;
+    int64_t N, ldn;
+    T h;
+    int L, D;
+    const T* prm;
+    T *Wq, *Wv, *Wa, *Wg;
+};
+
+template <int METHOD, bool UNIT>
+__global__ void __launch_bounds__(SB) k_custom_integrate(IntPrm prm) {
+    const int64_t n = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const int64_t ld = prm.N;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    const Chain c{prm.Wq + n, prm.Wv + n, prm.Wa + n, prm.Wg + n, ld, D, prm.prm};
+    T *q = prm.q + n, *p = prm.p + n;
+    T* vo = prm.v_out ? prm.v_out + n : nullptr;
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T x[CH], y[CH];
+        load_rows<CH>(q, prm.ldn, j0, D, x);
+        load_rows<CH>(p, prm.ldn, j0, D, y);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (j0 + k < D) {
+                c.q[(int64_t)(j0 + k) * ld] = x[k];
+                c.v[(int64_t)(j0 + k) * ld] = UNIT ? y[k] : y[k] / m;
+            }
+    }
+    trajectory<METHOD, UNIT>(c, m, prm.h, prm.L);
+    const T* vsrc = METHOD == PBBI_STORMER_VERLET ? c.a : c.v;
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T x[CH], v[CH];
+        load_rows<CH>(c.q, ld, j0, D, x);
+        load_rows<CH>(vsrc, ld, j0, D, v);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = j0 + k;
+            if (j < D) {
+                const T vj = final_v<METHOD>(x[k], v[k], prm.h);
+                q[(int64_t)j * prm.ldn] = x[k];
+                p[(int64_t)j * prm.ldn] = UNIT ? vj : vj * m;
+                if (vo) vo[(int64_t)j * prm.ldn] = vj;
+            }
+        }
+    }
+}
+
+struct EvalPrm {
+    const T* q;
+    const T* p;
+    const T* mass;
+    T* U_out;
+    T* grad_out;
+    T* w_out;
+    int64_t N, ldn;
+    int D, mode;  // 0: eval (U, grad); 1: energy H / w; 2: ratio finish U_out = exp(U_out - H)
+    const T* prm;
+};
+
+__global__ void __launch_bounds__(SB) k_custom_eval(EvalPrm prm) {
+    const int64_t n = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const Col<const T> q{prm.q + n, prm.ldn};
+    if (prm.mode == 0) {
+        if (prm.U_out) prm.U_out[n] = user::potential(q, D, prm.prm);
+        if (prm.grad_out) {
+            Col<T> g{prm.grad_out + n, prm.ldn};
+            user::gradient(q, g, D, prm.prm);
+        }
+        return;
+    }
+    T pp = T(0);
+    for (int j0 = 0; j0 < D; j0 += CH) {
+        T p[CH];
+        load_rows<CH>(prm.p + n, prm.ldn, j0, D, p);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (j0 + k < D) pp += p[k] * p[k];
+    }
+    const T m = prm.mass ? prm.mass[n] : T(1);
+    const T H = T(0.5) * pp / m + user::potential(q, D, prm.prm);
+    if (prm.mode == 1) {
+        if (prm.U_out) prm.U_out[n] = H;
+        if (prm.w_out) prm.w_out[n] = exp(-H);  // src/HMC.py:103
+    } else {
+        prm.U_out[n] = exp(prm.U_out[n] - H);  // src/HMC.py:115
+    }
+}
+
+struct Workspace {  // stream-ordered scratch for one call
+    hipStream_t st;
+    std::vector<void*> ptrs;
+    explicit Workspace(hipStream_t s) : st(s) {}
+    T* get(size_t elems) {
+        void* p = nullptr;
+        if (hipMallocAsync(&p, (elems ? elems : 2) * sizeof(T), st) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+    ~Workspace() {
+        for (void* p : ptrs) (void)hipFreeAsync(p, st);
+    }
+};
+
+inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + SB - 1) / SB)); }
+
+template <typename F>
+void with_method_unit(int method, bool unit, F&& f) {
+    if (method == PBBI_LEAPFROG) {
+        if (unit) f(std::integral_constant<int, PBBI_LEAPFROG>{}, std::true_type{});
+        else f(std::integral_constant<int, PBBI_LEAPFROG>{}, std::false_type{});
+    } else {
+        if (unit) f(std::integral_constant<int, PBBI_STORMER_VERLET>{}, std::true_type{});
+        else f(std::integral_constant<int, PBBI_STORMER_VERLET>{}, std::false_type{});
+    }
+}
+
+}  // namespace pbbi_custom
+
+// ---- the plugin's exported surface (resolved by pbbi_potential_create_custom) -----------------
+// return value: 0, a hipError_t, or -1 when the workspace could not be allocated
+extern "C" {
+
+int pbbi_plugin_abi(void) { return PBBI_PLUGIN_ABI; }
+int pbbi_plugin_dtype(void) { return sizeof(T) == 8 ? PBBI_F64 : PBBI_F32; }
+
+int pbbi_plugin_hmc_iter(const IterArgs* a) {
+    using namespace pbbi_custom;
+    const pbbi_potential* pot = a->pot;
+    Workspace ws(a->stream);
+    const size_t slab = (size_t)pot->D * a->N;
+    T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);
+    if (!Wq || !Wv || !Wa || !Wg) return -1;
+    HmcPrm prm{(const T*)a->q_in, (const T*)a->p_in, (const T*)a->u_in, (const T*)a->mass,
+               (T*)a->q_out, (T*)a->p_out, (T*)a->ratio_out, a->reject_out,
+               a->N, a->ldn_in, a->ldn_out, (T)a->h, a->L, pot->D, a->flags, a->rng,
+               a->seed, a->iter, a->chain0, a->kT, (const T*)pot->d_params, Wq, Wv, Wa, Wg};
+    with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+        hipLaunchKernelGGL((k_custom_hmc<decltype(meth)::value, decltype(unit)::value>),
+                           grid_for(a->N), dim3(SB), 0, a->stream, prm);
+    });
+    return (int)hipGetLastError();
+}
+
+int pbbi_plugin_integrate(const IntegrateArgs* a) {
+    using namespace pbbi_custom;
+    const pbbi_potential* pot = a->pot;
+    Workspace ws(a->stream);
+    const size_t slab = (size_t)pot->D * a->N;
+    T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);
+    if (!Wq || !Wv || !Wa || !Wg) return -1;
+    IntPrm prm{(T*)a->q, (T*)a->p, (const T*)a->mass, (T*)a->v_out, a->N, a->ldn, (T)a->h, a->L,
+               pot->D, (const T*)pot->d_params, Wq, Wv, Wa, Wg};
+    with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+        hipLaunchKernelGGL((k_custom_integrate<decltype(meth)::value, decltype(unit)::value>),
+                           grid_for(a->N), dim3(SB), 0, a->stream, prm);
+    });
+    return (int)hipGetLastError();
+}
+
+int pbbi_plugin_eval(const EvalArgs* a, int mode) {
+    using namespace pbbi_custom;
+    const pbbi_potential* pot = a->pot;
+    EvalPrm prm{(const T*)a->q, (const T*)a->p, (const T*)a->mass, (T*)a->U_out, (T*)a->grad_out,
+                (T*)a->w_out, a->N, a->ldn, pot->D, mode, (const T*)pot->d_params};
+    hipLaunchKernelGGL(k_custom_eval, grid_for(a->N), dim3(SB), 0, a->stream, prm);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

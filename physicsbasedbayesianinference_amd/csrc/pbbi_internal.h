@@ -7,7 +7,14 @@
 
 #include "pbbi.h"
 
-enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3 };
+enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3, KIND_CUSTOM = 4 };
+
+// layout version of the structs a user-potential plugin (pbbi_custom.h) shares with libpbbi.so
+#define PBBI_PLUGIN_ABI 1
+
+struct IterArgs;
+struct IntegrateArgs;
+struct EvalArgs;
 
 struct pbbi_potential {
     int kind;
@@ -26,6 +33,13 @@ struct pbbi_potential {
     int DPAD_big;      // D padded to a multiple of 128 (0 = path not built)
     void* d_big_PT;    // DPAD x DPAD, P transposed ([k][i]), zero padded, handle dtype
     void* d_big_mu;    // DPAD, zero padded
+    // user-defined potential (KIND_CUSTOM): kernels live in a plugin .so built by custom.py
+    void* plugin;      // dlopen handle
+    void* d_params;    // n_params elements (dtype) handed to the user's functions, or nullptr
+    int n_params;
+    int (*plugin_hmc_iter)(const IterArgs*);
+    int (*plugin_integrate)(const IntegrateArgs*);
+    int (*plugin_eval)(const EvalArgs*, int mode);
 };
 
 // ---- error plumbing ---------------------------------------------------------

@@ -9,8 +9,8 @@ loops of src/integrator.py:105-120 and :142-163 are replaced by one fused HIP ke
 launch over the whole ensemble (`pbbi_leapfrog` / `pbbi_stormer_verlet`).
 
 `gradient` must come from a potential descriptor (`pot.gradient`, or the descriptor
-itself): arbitrary Python callables cannot run inside a GPU kernel and are rejected
-with a TypeError -- there is no host fallback.  `gradient=None` selects the reference's
+itself, including custom.CustomPotential for user-written potentials): arbitrary Python callables
+cannot run inside a GPU kernel and are rejected with a TypeError -- there is no host fallback.  `gradient=None` selects the reference's
 N-body gravity mode (src/integrator.py:57-59), which is not an HMC path and is out of
 scope: NotImplementedError.
 """
@@ -34,7 +34,8 @@ def resolve_potential(fn, what="gradient"):
         f"{what} must be a potential descriptor of physicsbasedbayesianinference_amd.potential "
         f"(e.g. GaussianDense(mean, cov=cov), Harmonic(k), Rosenbrock(D)) or one of its bound "
         f"methods; got {fn!r}.  Arbitrary Python callables cannot execute inside the HIP "
-        f"kernels and this package has no CPU fallback.")
+        f"kernels and this package has no CPU fallback: state the function as C++ source with "
+        f"custom.CustomPotential(D, source, params) instead.")
 
 
 def mass_or_none(mass, N, dtype, device):

@@ -835,3 +835,102 @@ def test_streaming_lane_path_philox_and_fp32(P, lib):
         U, g = pot32.value_and_gradient(q)
         U_or, g_or = orc.potential(op, q, want_grad=True)
         assert scaled_err(U, U_or) <= 1e-5 and scaled_err(g, g_or) <= 1e-5
+
+
+# ------------------------------------------------------------------ user-defined potentials
+@pytest.mark.parametrize("method,mass", [("Leapfrog", False), ("Leapfrog", True), ("Stormer-Verlet", True)])
+def test_custom_potential_polynomial_bit_exact(P, lib, method, mass):
+    """CustomPotential: the user's C++ source inlined into the plugin kernels vs the same source
+    compiled for the host inside the oracle.  Polynomial potential => bit-identical."""
+    from custom_sources import QUARTIC
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    D, N, L, h = 11, 300, 9, 0.07
+    prm = [1.5, 0.75]
+    pot, op = CustomPotential(D, QUARTIC, prm), orc.pot_custom(QUARTIC, D, prm)
+    rs = np.random.RandomState(5)
+    q, p, u = rs.standard_normal((D, N)), rs.standard_normal((D, N)), rs.uniform(size=N)
+    u[::4] = 1.5  # forced rejects
+    m = (1.0 + (np.arange(N) % 4) * 0.5) if mass else None
+    for compat in (True, False):
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, m, h, L, compat=compat)
+        q_or, p_or = q.copy(), p.copy()
+        r_or, rej_or = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L,
+                                      compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(rej, rej_or) and 0 < rej.sum() < N
+        assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
+        assert np.max(np.abs(np.log(ratio) - np.log(r_or))) < 1e-8
+    U, g = pot.value_and_gradient(q)
+    U_or, g_or = orc.potential(op, q, want_grad=True)
+    assert np.array_equal(U, U_or) and np.array_equal(g, g_or)
+    assert pot.check_gradient(q[:, :20]) < 1e-6
+    # weights / Hamiltonians through the class API
+    ens = P.Ensemble(D, N)
+    ens.q, ens.p = q.copy(), p.copy()
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, 1.0, 0.1, None, potential=pot, verbose=False)
+    w_or, _ = orc.weights(op, q, p, m)
+    assert np.allclose(hmc.getWeights(q, p), w_or, rtol=1e-13)
+
+
+def test_custom_potential_logistic_regression(P, lib):
+    """A Bayesian model as a user potential: logistic regression, the data set travels in `params`.
+    exp / log1p differ in the last ulp between the device and the host libm: 1e-12 tolerance.
+    Sampling (in-kernel draws) is replayed by the oracle from the device draws, and the posterior
+    mean agrees with a long NumPy-stream run of the same sampler (statistical check)."""
+    from custom_sources import LOGISTIC, logistic_numpy, logistic_problem
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    X, y, lam, prm = logistic_problem(M=40, D=5)
+    D, N = X.shape[1], 500
+    pot, op = CustomPotential(D, LOGISTIC, prm), orc.pot_custom(LOGISTIC, D, prm)
+    rs = np.random.RandomState(1)
+    q = rs.standard_normal((D, N))
+    U, g = pot.value_and_gradient(q)
+    Un, gn = logistic_numpy(X, y, lam, q)
+    assert scaled_err(U, Un) <= 1e-12 and scaled_err(g, gn) <= 1e-12
+    assert pot.check_gradient(q[:, :10]) < 1e-6
+    S, L, h, seed = 4, 8, 0.1, 3
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 1.0)
+    qs = device_normal(lib, seed, lib.STREAM_POSITION, 0, 0, D, N, 1.0)
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 0, D, N, 1.0, np.ones(N))
+        u = device_uniform(lib, seed, i, 0, N)
+        _, rej = orc.hmc_iter(op, "Leapfrog", qs, p, u, None, h, L)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert scaled_err(samples[:, :, i], qs) <= 1e-11 and scaled_err(momenta[:, :, i], p) <= 1e-11
+    assert 0.0 < hmc.reject_masks.mean() < 0.5
+    # posterior mean: 4000 chains x 40 kept draws vs the Laplace-free ground truth from a long
+    # independent run in the other RNG mode
+    ens = P.Ensemble(D, 4000)
+    hmc = P.HMC(ens, 0.8, 0.1, None, potential=pot, rng="philox", seed=9, verbose=False)
+    s_dev, _ = hmc.getSamples(60, 1.0 / kB, 1.0, device_output=True)
+    mean, var = hmc.sampleMoments(s_dev[:, :, 20:])
+    np.random.seed(4)
+    ens2 = P.Ensemble(D, 4000)
+    s2, _ = P.HMC(ens2, 0.8, 0.1, None, potential=pot, verbose=False).getSamples(60, 1.0 / kB, 1.0)
+    assert np.max(np.abs(mean - s2[:, :, 20:].mean(axis=(1, 2)))) < 0.02
+    assert np.max(np.abs(var / s2[:, :, 20:].var(axis=(1, 2)) - 1.0)) < 0.05
+
+
+def test_custom_potential_fp32_and_errors(P, lib):
+    from custom_sources import QUARTIC
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    D, N = 7, 100
+    pot32, op = CustomPotential(D, QUARTIC, [1.0, 0.5], dtype="float32"), orc.pot_custom(QUARTIC, D, [1.0, 0.5])
+    rs = np.random.RandomState(2)
+    q = rs.standard_normal((D, N)).astype(np.float32).astype(np.float64)
+    p = rs.standard_normal((D, N)).astype(np.float32).astype(np.float64)
+    ens = P.Ensemble(D, N)
+    ens.q, ens.p = q.copy(), p.copy()
+    qi, pi = P.Leapfrog(ens, 0.05, 0.5 + 1e-6, pot32).integrate()
+    q2, p2 = q.copy(), p.copy()
+    orc.integrate(op, "Leapfrog", q2, p2, None, 0.05, 10)
+    assert scaled_err(qi, q2) <= 2e-5 and scaled_err(pi, p2) <= 2e-5
+    with pytest.raises(RuntimeError, match="hipcc failed"):
+        CustomPotential(D, "template <class Q> PBBI_FN T potential(const Q& q, int D, const T* prm) { return nope; }")
+    with pytest.raises(lib.PbbiError):   # a file that is not a plugin
+        h = C.c_void_p()
+        lib.call("pbbi_potential_create_custom", b"/nonexistent/plugin.so", D, None, 0, lib.F64, 0,
+                 C.byref(h))
