@@ -203,6 +203,56 @@ class HMC:
             return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
         return self._to_dns(samples), self._to_dns(momenta)
 
+    def adaptStepSize(self, temperature, qStd, target=0.8, iterations=60, seed=None, chain0=0,
+                      gamma=0.05, t0=10.0, kappa=0.75):
+        """Step-size adaptation by dual averaging (Hoffman & Gelman 2014, Alg. 5) on the
+        ENSEMBLE-mean acceptance probability -- SURVEY 8f row 2 (planned in the reference's
+        WeekPlan.md:16-17; described in NotesOnParticleBasedHMC.pdf 0.1.2), not a reference
+        feature.  Runs `iterations` warm-up iterations with in-kernel draws (one fused launch each;
+        only the scalar mean(min(1, ratio)) leaves the GPU, all-reduced over the process group when
+        the ensemble is sharded), keeps simulTime fixed (numSteps = int(simulTime/stepSize) follows
+        the step), then sets self.stepSize / the integrator's to the averaged step and returns it.
+        The warm-up state is discarded."""
+        import torch
+        pot, ens = self._pot, self.ensemble
+        D, N = ens.numDimensions, ens.numParticles
+        if N == 0:
+            return float(self.stepSize)
+        seed = self.seed if seed is None else int(seed)
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+        kT = float(boltzmannConst * temperature)
+        q_state = empty((D, N), dt, dev)
+        sample, ratio = empty((1, D, N), dt, dev), empty((1, N), dt, dev)
+        md = self._mass()
+        mptr = md.data_ptr() if md is not None else None
+        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, int(chain0), D, N, N,
+                  float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
+        sharded = torch.distributed.is_available() and torch.distributed.is_initialized()
+        h = float(self.stepSize)
+        mu, hbar, log_hbar = np.log(10.0 * h), 0.0, 0.0
+        for m in range(1, int(iterations) + 1):
+            L = max(1, int(self.simulTime / h))
+            _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
+                      sample.data_ptr(), None, None, ratio.data_ptr(), N, N, h, L, 1, 0, seed,
+                      (1 << 40) + m, int(chain0), kT, stream)  # counters disjoint from getSamples'
+            acc = torch.nan_to_num(torch.clamp(ratio[0].double(), max=1.0), nan=0.0).sum()
+            cnt = torch.tensor(float(N), dtype=torch.float64, device=acc.device)
+            if sharded:
+                both = torch.stack([acc, cnt])
+                torch.distributed.all_reduce(both)
+                acc, cnt = both[0], both[1]
+            alpha = float(acc / cnt)
+            hbar = (1.0 - 1.0 / (m + t0)) * hbar + (target - alpha) / (m + t0)
+            log_h = mu - np.sqrt(m) / gamma * hbar
+            eta = m ** (-kappa)
+            log_hbar = eta * log_h + (1.0 - eta) * log_hbar
+            h = float(np.exp(log_h))
+        h = float(np.exp(log_hbar))
+        self.stepSize = self.integrator.stepSize = h
+        self.integrator.numSteps = int(self.simulTime / h)
+        return h
+
     def sampleMoments(self, samples_dns):
         """Per-dimension (mean, variance) over every draw of every chain, computed on the GPU from
         the (D, N, S) device view that getSamples(device_output=True) returns -- the sample sink

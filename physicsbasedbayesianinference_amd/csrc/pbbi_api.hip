@@ -104,23 +104,23 @@ int plugin_rc(int rc) {
 int route_hmc(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
-    return route_hmc(a);
+    return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
 }
 int route_integrate(const IntegrateArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_integrate(&a)) : PBBI_OK;
-    return route_integrate(a);
+    return is_big(pot) ? big_integrate(a) : is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
 }
 int route_eval(const EvalArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_eval(&a, 0)) : PBBI_OK;
-    return route_eval(a);
+    return is_big(pot) ? big_eval(a) : is_dense(pot) ? dense_eval(a) : lane_eval(a);
 }
 int route_energy(const EvalArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM)
         return a.N ? plugin_rc(pot->plugin_eval(&a, a.ratio_finish ? 2 : 1)) : PBBI_OK;
-    return route_energy(a);
+    return is_big(pot) ? big_energy(a) : is_dense(pot) ? dense_energy(a) : lane_energy(a);
 }
 
 // ---- small utility kernels ---------------------------------------------------

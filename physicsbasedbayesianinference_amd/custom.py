@@ -39,7 +39,9 @@ import numpy as np
 from . import _lib
 from .potential import Potential, _dptr
 
-__all__ = ["CustomPotential", "compile_plugin", "plugin_source"]
+__all__ = ["CustomPotential", "compile_plugin", "plugin_source", "coin_toss_posterior",
+           "logistic_regression_posterior", "COIN_TOSS_SOURCE", "LOGISTIC_REGRESSION_SOURCE",
+           "EXAMPLE_SOURCE"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
@@ -122,3 +124,99 @@ class CustomPotential(Potential):
             dq[j] = eps
             fd[j] = (self(q2 + dq) - self(q2 - dq)) / (2 * eps)
         return float(np.max(np.abs(g - fd)) / max(1.0, float(np.max(np.abs(fd)))))
+
+
+# ---------------------------------------------------------------------------------------------
+# A first library of likelihoods on top of the source mechanism (the model ->
+# potential boundary; the reference shows the pattern with NumPyro's log_density in
+# samples/NumpyroExamples/CoinToss/CoinTossExample.py:75-107).
+
+EXAMPLE_SOURCE = """
+template <class Q>
+PBBI_FN T potential(const Q& q, int D, const T* prm) {
+    T s = 0;
+    for (int j = 0; j < D; ++j) s += ((q[j] * q[j]) * (q[j] * q[j]));
+    return (T(0.25) * prm[0]) * s;
+}
+template <class Q, class G>
+PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
+    for (int j = 0; j < D; ++j) g[j] = prm[0] * ((q[j] * q[j]) * q[j]);
+}
+"""
+
+# Coin toss: theta ~ Beta(a, b), k heads in n tosses, sampled in x = logit(theta) (unconstrained;
+# the Jacobian theta (1 - theta) is included):  U(x) = A softplus(-x) + B softplus(x),
+# A = k + a, B = n - k + b; prm = [A, B].  D independent coins share the constants.
+COIN_TOSS_SOURCE = """
+PBBI_FN T softplus(T z) { return (z > 0 ? z : T(0)) + log1p(exp(-fabs(z))); }
+template <class Q>
+PBBI_FN T potential(const Q& q, int D, const T* prm) {
+    T s = 0;
+    for (int j = 0; j < D; ++j) s += prm[0] * softplus(-q[j]) + prm[1] * softplus(q[j]);
+    return s;
+}
+template <class Q, class G>
+PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
+    for (int j = 0; j < D; ++j) {
+        const T sig = T(1) / (T(1) + exp(-q[j]));
+        g[j] = prm[1] * sig - prm[0] * (T(1) - sig);
+    }
+}
+"""
+
+# Bayesian logistic regression: prm = [M, X (M x D row-major), y in {0,1} (M), prior precision];
+# U(w) = sum_i softplus(x_i.w) - y_i x_i.w + 0.5 lam |w|^2
+LOGISTIC_REGRESSION_SOURCE = """
+template <class Q>
+PBBI_FN T potential(const Q& q, int D, const T* prm) {
+    const int M = (int)prm[0];
+    const T* X = prm + 1;
+    const T* y = X + (long)M * D;
+    const T lam = y[M];
+    T s = 0;
+    for (int i = 0; i < M; ++i) {
+        T z = 0;
+        for (int j = 0; j < D; ++j) z += X[i * D + j] * q[j];
+        s += ((z > 0 ? z : T(0)) + log1p(exp(-fabs(z)))) - y[i] * z;
+    }
+    T r = 0;
+    for (int j = 0; j < D; ++j) r += q[j] * q[j];
+    return s + (T(0.5) * lam) * r;
+}
+template <class Q, class G>
+PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
+    const int M = (int)prm[0];
+    const T* X = prm + 1;
+    const T* y = X + (long)M * D;
+    const T lam = y[M];
+    for (int j = 0; j < D; ++j) g[j] = lam * q[j];
+    for (int i = 0; i < M; ++i) {
+        T z = 0;
+        for (int j = 0; j < D; ++j) z += X[i * D + j] * q[j];
+        const T w = T(1) / (T(1) + exp(-z)) - y[i];
+        for (int j = 0; j < D; ++j) g[j] += w * X[i * D + j];
+    }
+}
+"""
+
+
+def coin_toss_posterior(heads, tosses, a=1.0, b=1.0, D=1, **kw):
+    """Posterior of a coin's bias theta ~ Beta(a, b) after `heads` in `tosses`, as a potential in
+    x = logit(theta); theta = 1/(1+exp(-x)) of the samples is Beta(heads+a, tosses-heads+b)."""
+    return CustomPotential(D, COIN_TOSS_SOURCE, [heads + a, tosses - heads + b], **kw)
+
+
+def logistic_regression_params(X, y, prior_precision=1.0):
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).ravel()
+    if X.ndim != 2 or y.size != X.shape[0]:
+        raise ValueError("X must be (M, D) and y (M,)")
+    return np.concatenate([[float(X.shape[0])], X.ravel(), y, [float(prior_precision)]])
+
+
+def logistic_regression_posterior(X, y, prior_precision=1.0, **kw):
+    """-log posterior of the weights of y_i ~ Bernoulli(sigmoid(x_i . w)), w ~ N(0, I/prior_precision);
+    the data set rides in the potential's parameter array."""
+    X = np.asarray(X, dtype=np.float64)
+    return CustomPotential(X.shape[1], LOGISTIC_REGRESSION_SOURCE,
+                           logistic_regression_params(X, y, prior_precision), **kw)

@@ -934,3 +934,37 @@ def test_custom_potential_fp32_and_errors(P, lib):
         h = C.c_void_p()
         lib.call("pbbi_potential_create_custom", b"/nonexistent/plugin.so", D, None, 0, lib.F64, 0,
                  C.byref(h))
+
+
+def test_coin_toss_posterior(P):
+    """SURVEY 8f row 1's first model (samples/NumpyroExamples/CoinToss): Beta(2,2) prior, 7 heads
+    in 10 tosses, sampled in logit space; sigmoid(samples) must be Beta(9, 5)."""
+    from physicsbasedbayesianinference_amd.custom import coin_toss_posterior
+    pot = coin_toss_posterior(7, 10, a=2.0, b=2.0)
+    ens = P.Ensemble(1, 8192)
+    hmc = P.HMC(ens, 1.0, 0.1, None, potential=pot, rng="philox", seed=2, verbose=False)
+    s, _ = hmc.getSamples(40, 1.0 / kB, 1.0)
+    theta = 1.0 / (1.0 + np.exp(-s[0, :, 10:]))
+    A, B = 9.0, 5.0
+    assert abs(theta.mean() - A / (A + B)) < 3e-3
+    assert abs(theta.var() / (A * B / ((A + B) ** 2 * (A + B + 1))) - 1.0) < 0.05
+    assert hmc.acceptRate > 0.95
+
+
+def test_dual_averaging_step_size(P):
+    """adaptStepSize: from a far too small and a far too large step the ensemble-mean acceptance of
+    a following run lands near the target (dense Gaussian, D = 48)."""
+    D, N = 48, 4096
+    rs = np.random.RandomState(0)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + 0.1 * np.eye(D))
+    pot = P.GaussianDense(None, precision=0.5 * (Pm + Pm.T), const=0.0)
+    steps = []
+    for h0 in (0.01, 1.5):
+        hmc = P.HMC(P.Ensemble(D, N), 1.0, h0, None, potential=pot, rng="philox", seed=5, verbose=False)
+        h = hmc.adaptStepSize(1.0 / kB, 1.0, target=0.8, iterations=150)
+        assert hmc.stepSize == h and hmc.integrator.numSteps == int(1.0 / h)
+        hmc.getSamples(20, 1.0 / kB, 1.0)
+        assert abs(np.minimum(1.0, hmc.ratios[5:]).mean() - 0.8) < 0.1, (h0, h)
+        steps.append(h)
+    assert abs(steps[0] / steps[1] - 1.0) < 0.35
