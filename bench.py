@@ -258,10 +258,18 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # rehearsal switch for a one-GPU box: PBBI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses
+    # gloo, to exercise the world_size > 1 code path without RCCL (numbers are then meaningless)
+    rehearse = os.environ.get("PBBI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import physicsbasedbayesianinference_amd as P
     from physicsbasedbayesianinference_amd import _lib
