@@ -968,3 +968,37 @@ def test_dual_averaging_step_size(P):
         assert abs(np.minimum(1.0, hmc.ratios[5:]).mean() - 0.8) < 0.1, (h0, h)
         steps.append(h)
     assert abs(steps[0] / steps[1] - 1.0) < 0.35
+
+
+@pytest.mark.parametrize("D,N,mass,compat", [(32, 2500, False, True), (32, 333, True, False),
+                                             (23, 1000, False, True)])
+def test_rosenbrock_run_with_many_rejections_bitexact(P, lib, D, N, mass, compat):
+    """pbbi_hmc_run on the two-lane kernel (chains partitioned over internal streams when the
+    ensemble is large) with a step large enough for frequent rejections: replayed by the oracle
+    from the device draws, and by per-iteration pbbi_hmc_iter calls with the same draws --
+    bit-exact, including chains rejected after earlier rejections."""
+    S, L, h, seed, chain0, iter0 = 6, 10, 0.05, 77, 12345, 3
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    m = (1.0 + (np.arange(N) % 3) * 0.5) if mass else None
+    ens = P.Ensemble(D, N)
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, compat=compat,
+                verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=chain0, iter0=iter0)
+    q = 0.0 + device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 0.3)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, iter0 + i, chain0, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, iter0 + i, chain0, N)
+        qg, pg, ratio_g, rej_g = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, m, h, L, compat=compat)
+        r_or, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L,
+                                 compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(hmc.reject_masks[i], rej) and np.array_equal(rej_g, rej)
+        assert np.array_equal(samples[:, :, i], q) and np.array_equal(momenta[:, :, i], p)
+        assert np.array_equal(qg, q) and np.array_equal(pg, p)
+        fin = np.isfinite(r_or) & (r_or > 0)
+        assert np.max(np.abs(np.log(hmc.ratios[i][fin]) - np.log(r_or[fin]))) < 1e-9
+        n_rej += int(rej.sum())
+    assert n_rej > S  # rejections in several iterations, including after earlier rejections

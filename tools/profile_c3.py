@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Config C3 (Rosenbrock d=32, 262144 chains), 6 HMC iterations: a small fixed workload for
+rocprofv3 PMC passes on k_ros2_hmc."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import physicsbasedbayesianinference_amd as P
+from physicsbasedbayesianinference_amd import _lib
+
+D, N, L, S = 32, 262144, 10, 6
+pot = P.Rosenbrock(D)
+q = 1.0 + 0.1 * torch.randn((D, N), dtype=torch.float64, device="cuda")
+samples = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
+mom = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
+rej = torch.empty((S, N), dtype=torch.uint8, device="cuda")
+_lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, samples.data_ptr(), mom.data_ptr(),
+          rej.data_ptr(), None, N, N, 0.01, L, S, 1, 1, 0, 0, 1.0, None)
+torch.cuda.synchronize()
+print("ok", float(rej.float().mean()))
