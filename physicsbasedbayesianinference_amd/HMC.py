@@ -203,6 +203,55 @@ class HMC:
             return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
         return self._to_dns(samples), self._to_dns(momenta)
 
+    def sampleChunks(self, numSamples, chunk, temperature, qStd, seed=None, chain0=0, iter0=0,
+                     spill_dir=None, momenta=False):
+        """Generator over a long in-kernel-draw run in chunks of `chunk` iterations (SURVEY 8f row 4:
+        at C2 scale 1000 draws are 64 GB, more than one wants resident or returned at once).  The
+        chain state stays on the GPU between chunks and the Philox iteration counter continues,
+        so the concatenated chunks are bit-identical to ONE getSamples(numSamples, rng="philox")
+        call.  Yields (samples, momenta_or_None) per chunk as (D, N, c) device views that are
+        OVERWRITTEN by the next chunk -- reduce them (sampleMoments) or copy them before
+        advancing.  With spill_dir every chunk is also written as samples_00000.npy, ... in the
+        reference's (D, N, c) layout (momenta_XXXXX.npy when momenta=True)."""
+        import os
+        pot, ens = self._pot, self.ensemble
+        D, N = ens.numDimensions, ens.numParticles
+        S, chunk = int(numSamples), max(1, int(chunk))
+        seed = self.seed if seed is None else int(seed)
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+        kT = float(boltzmannConst * temperature)
+        flags = _lib.COMPAT_P_FROM_OLDQ if self.compat else 0
+        md = self._mass()
+        mptr = md.data_ptr() if md is not None else None
+        q_state = empty((D, N), dt, dev)
+        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D, N, N,
+                  float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
+        c_alloc = min(chunk, max(S, 1))
+        samples = empty((c_alloc, D, N), dt, dev)
+        mom = empty((c_alloc, D, N), dt, dev) if momenta else None
+        reject = empty((c_alloc, N), np.uint8, dev)
+        if spill_dir is not None:
+            os.makedirs(spill_dir, exist_ok=True)
+        done, k, n_rej = 0, 0, 0.0
+        while done < S:
+            c = min(chunk, S - done)
+            _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
+                      samples.data_ptr(), mom.data_ptr() if momenta else None, reject.data_ptr(), None,
+                      N, N, float(self.stepSize), self.integrator.numSteps, c, flags, seed,
+                      int(iter0) + done, int(chain0), kT, stream)
+            n_rej += float(reject[:c].float().sum().item()) if N else 0.0
+            s_view = samples[:c].permute(1, 2, 0)
+            m_view = mom[:c].permute(1, 2, 0) if momenta else None
+            if spill_dir is not None:
+                np.save(os.path.join(spill_dir, f"samples_{k:05d}.npy"), self._to_dns(samples[:c]))
+                if momenta:
+                    np.save(os.path.join(spill_dir, f"momenta_{k:05d}.npy"), self._to_dns(mom[:c]))
+            done += c
+            k += 1
+            self.acceptRate = 1.0 - n_rej / (done * N) if N else None
+            yield s_view, m_view
+
     def adaptStepSize(self, temperature, qStd, target=0.8, iterations=60, seed=None, chain0=0,
                       gamma=0.05, t0=10.0, kappa=0.75):
         """Step-size adaptation by dual averaging (Hoffman & Gelman 2014, Alg. 5) on the

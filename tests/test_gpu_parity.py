@@ -1002,3 +1002,27 @@ def test_rosenbrock_run_with_many_rejections_bitexact(P, lib, D, N, mass, compat
         assert np.max(np.abs(np.log(hmc.ratios[i][fin]) - np.log(r_or[fin]))) < 1e-9
         n_rej += int(rej.sum())
     assert n_rej > S  # rejections in several iterations, including after earlier rejections
+
+
+def test_sample_chunks_equal_one_run(P, tmp_path):
+    """sampleChunks: chunked long run (state and Philox counters carried on the GPU) == one
+    getSamples call, bit for bit; the .npy spill holds the same (D, N, c) blocks."""
+    D, N, S = 16, 300, 11
+    rs = np.random.RandomState(1)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    pot = P.GaussianDense(rs.standard_normal(D), precision=0.5 * (Pm + Pm.T), const=0.0)
+    kw = dict(potential=pot, rng="philox", seed=8, verbose=False)
+    ref_s, ref_m = P.HMC(P.Ensemble(D, N), 1.0, 0.25, None, **kw).getSamples(S, 1 / kB, 1.0, chain0=7, iter0=2)
+    hmc = P.HMC(P.Ensemble(D, N), 1.0, 0.25, None, **kw)
+    got_s, got_m = [], []
+    for s_dev, m_dev in hmc.sampleChunks(S, 4, 1 / kB, 1.0, chain0=7, iter0=2, spill_dir=str(tmp_path),
+                                         momenta=True):
+        got_s.append(s_dev.cpu().numpy().copy())
+        got_m.append(m_dev.cpu().numpy().copy())
+    assert [g.shape[2] for g in got_s] == [4, 4, 3]
+    assert np.array_equal(np.concatenate(got_s, axis=2), ref_s)
+    assert np.array_equal(np.concatenate(got_m, axis=2), ref_m)
+    spilled = np.concatenate([np.load(tmp_path / f"samples_{k:05d}.npy") for k in range(3)], axis=2)
+    assert np.array_equal(spilled, ref_s)
+    assert 0.0 < hmc.acceptRate <= 1.0
