@@ -102,6 +102,9 @@ def main_c3(args):
     from physicsbasedbayesianinference_amd import _lib
     d, N, h, L = 32, 262144 if args.chains == N_PER_GPU else args.chains, 0.01, 10
     K, W = args.steps, max(args.warmup, 100)
+    # default: kick-drift-kick with FMAs (PBBI_KDK_FMA, ~1e-13 from the reference's operation order);
+    # --exact-order times the bit-exact velocity-Verlet kernel instead
+    flags = _lib.COMPAT_P_FROM_OLDQ | (0 if args.exact_order else _lib.KDK_FMA)
     pot = P.Rosenbrock(d)
     stream = torch.cuda.current_stream().cuda_stream
     q = torch.empty((d, N), dtype=torch.float64, device="cuda")
@@ -115,7 +118,7 @@ def main_c3(args):
 
     def run(S, it0):
         _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
-                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, 1, 7, it0, 0, 1.0, stream)
+                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, 7, it0, 0, 1.0, stream)
     # this kernel's iterations are ~80 us: the chip needs a few hundred of them to settle its clock
     # (measured: the same 100 iterations run 10-15 % faster when they follow ~25 ms of the same work)
     for _ in range(3):
@@ -133,6 +136,8 @@ def main_c3(args):
         "value": K * L * N / t, "unit": "leapfrog-steps*chains/s", "n_gpus": 1, "steps": K,
         "warmup": 3 * W, "ms_per_step": t * 1e3 / K, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C3: Rosenbrock d=32, 262144 chains, L=10, h=0.01",
+                   "integrator_form": "velocity-Verlet, reference operation order (bit-exact)"
+                   if args.exact_order else "kick-drift-kick with FMA (PBBI_KDK_FMA)",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
         "roofline": {"bound": "hbm", "kernel": "k_ros2_hmc<unit mass, D=32> (two lanes per chain)",
                      "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -242,6 +247,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "stream"],
                     help="c2 (default, the BASELINE metric) or c3 (Rosenbrock d=32, 262144 chains: "
                          "the HBM-bound chain-per-lane kernel; extra, not the headline line)")
+    ap.add_argument("--exact-order", action="store_true",
+                    help="--workload c3: the bit-exact velocity-Verlet kernel instead of PBBI_KDK_FMA")
     ap.add_argument("--dim", type=int, default=128, help="--workload stream: dimension")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
     args = ap.parse_args()

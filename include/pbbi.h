@@ -66,7 +66,14 @@ enum { PBBI_LEAPFROG = 0, PBBI_STORMER_VERLET = 1 };
 enum {
     /* reproduce src/HMC.py:176: a rejected chain's stored momentum is its OLD POSITION.
      * Without the flag the stored momentum of a rejected chain is the drawn momentum. */
-    PBBI_COMPAT_P_FROM_OLDQ = 1
+    PBBI_COMPAT_P_FROM_OLDQ = 1,
+    /* Leapfrog only, opt-in throughput form: integrate in kick-drift-kick form with fused
+     * multiply-adds (state q and the half-step velocity; 2 instead of 7 fp64 instructions per
+     * element-step for the updates, no acceleration array).  Algebraically the reference's
+     * velocity-Verlet (src/integrator.py:105-120); results agree to ~1e-13 relative instead of bit
+     * for bit, accept masks as before.  Honoured by the two-lane Rosenbrock kernel (config C3);
+     * the MFMA kernels always integrate this way, the other chain-per-lane kernels ignore it. */
+    PBBI_KDK_FMA = 2
 };
 enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2 };
 

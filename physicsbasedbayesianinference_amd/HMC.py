@@ -33,12 +33,13 @@ __all__ = ["HMC"]
 
 class HMC:
     def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
-                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True):
+                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=False):
         self.ensemble = ensemble
         self.simulTime = simulTime
         self.stepSize = stepSize
         self.density = density
         self.compat = bool(compat)
+        self.kdk_fma = bool(kdk_fma)  # PBBI_KDK_FMA: throughput form of Leapfrog (include/pbbi.h)
         self.rng = rng
         self.seed = int(seed)
         self.verbose = verbose
@@ -140,7 +141,7 @@ class HMC:
         seed = self.seed if seed is None else int(seed)
         L = self.integrator.numSteps
         h = float(self.stepSize)
-        flags = _lib.COMPAT_P_FROM_OLDQ if self.compat else 0
+        flags = (_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0)
         dev, dt = pot.device, pot.dtype
         stream = stream_ptr(dev)
 
@@ -221,7 +222,7 @@ class HMC:
         dev, dt = pot.device, pot.dtype
         stream = stream_ptr(dev)
         kT = float(boltzmannConst * temperature)
-        flags = _lib.COMPAT_P_FROM_OLDQ if self.compat else 0
+        flags = (_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0)
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
         q_state = empty((D, N), dt, dev)

@@ -14,6 +14,7 @@ OK = 0
 F64, F32 = 0, 1
 LEAPFROG, STORMER_VERLET = 0, 1
 COMPAT_P_FROM_OLDQ = 1
+KDK_FMA = 2
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
 
 

@@ -1026,3 +1026,31 @@ def test_sample_chunks_equal_one_run(P, tmp_path):
     spilled = np.concatenate([np.load(tmp_path / f"samples_{k:05d}.npy") for k in range(3)], axis=2)
     assert np.array_equal(spilled, ref_s)
     assert 0.0 < hmc.acceptRate <= 1.0
+
+
+@pytest.mark.parametrize("D,N,mass", [(32, 3000, False), (27, 500, True)])
+def test_rosenbrock_kdk_fma_form(P, lib, D, N, mass):
+    """PBBI_KDK_FMA (kick-drift-kick with fused multiply-adds, the two-lane kernel's throughput
+    form): same integrator algebraically, so q, p agree with the oracle's velocity-Verlet to 1e-12
+    (fp64 tolerance for this mode) and the accept masks are equal."""
+    S, L, h, seed = 5, 10, 0.03, 5
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    m = (1.0 + (np.arange(N) % 3) * 0.5) if mass else None
+    ens = P.Ensemble(D, N)
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=True,
+                verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3)
+    q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 0, D, N, 0.3)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 0, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, i, 0, N)
+        _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
+        q = samples[:, :, i].copy()  # continue from the device state: compare step by step
+        n_rej += int(rej.sum())
+    assert n_rej > 0
