@@ -157,7 +157,14 @@ def main_stream(args):
     f32 = args.dtype == "f32"
     tdt, w, code = (torch.float32, 4, _lib.F32) if f32 else (torch.float64, 8, _lib.F64)
     K, W = args.steps, args.warmup
-    pot = P.Rosenbrock(d, dtype="float32" if f32 else "float64")
+    import numpy as np
+    if args.potential == "diag":
+        rs = np.random.RandomState(0)
+        pot = P.GaussianDiag(rs.standard_normal(d), prec=rs.uniform(0.5, 2.0, d), const=0.0,
+                             dtype="float32" if f32 else "float64")
+        h = 0.1
+    else:
+        pot = P.Rosenbrock(d, dtype="float32" if f32 else "float64")
     stream = torch.cuda.current_stream().cuda_stream
     q = torch.empty((d, N), dtype=tdt, device="cuda")
     _lib.call("pbbi_philox_normal", 7, _lib.STREAM_POSITION, 0, 0, d, N, N, 0.1, None, code, 0,
@@ -168,9 +175,11 @@ def main_stream(args):
     momenta = torch.empty((S_alloc, d, N), dtype=tdt, device="cuda")
     reject = torch.empty((S_alloc, N), dtype=torch.uint8, device="cuda")
 
+    flags = _lib.COMPAT_P_FROM_OLDQ | (0 if args.exact_order else _lib.KDK_FMA)
+
     def run(S, it0):
         _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
-                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, 1, 7, it0, 0, 1.0, stream)
+                  momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, 7, it0, 0, 1.0, stream)
     run(W, 0)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -182,12 +191,14 @@ def main_stream(args):
     bytes_launch = bytes_per_step_chain(d, L, w) * L * N
     design = (6 * L + 12) * w * d * N  # per launch: 6 accesses per element-step + init/energy/output sweeps
     print(json.dumps({
-        "metric": f"leapfrog-steps*chains/sec; Rosenbrock d={d}, ensemble={N}, {args.dtype} (streaming path)",
+        "metric": f"leapfrog-steps*chains/sec; {args.potential} d={d}, ensemble={N}, {args.dtype}",
         "value": K * L * N / t, "unit": "leapfrog-steps*chains/s", "n_gpus": 1, "steps": K,
         "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"Rosenbrock d={d}, {N} chains, L=10, h=0.01",
+        "config": {"workload": f"{args.potential} d={d}, {N} chains, L=10, h={h}",
+                   "integrator_form": "reference operation order" if args.exact_order
+                   else "PBBI_KDK_FMA where a kernel honours it",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "hbm", "kernel": "k_stream_hmc",
+        "roofline": {"bound": "hbm", "kernel": "k_lane_hmc / k_ros2_hmc (D <= 64, fp64) or k_stream_hmc",
                      "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "design_traffic_GBs": design / ks / 1e9, "launch_ms": ks * 1e3}}))
@@ -250,6 +261,8 @@ def main():
     ap.add_argument("--exact-order", action="store_true",
                     help="--workload c3: the bit-exact velocity-Verlet kernel instead of PBBI_KDK_FMA")
     ap.add_argument("--dim", type=int, default=128, help="--workload stream: dimension")
+    ap.add_argument("--potential", default="rosenbrock", choices=["rosenbrock", "diag"],
+                    help="--workload stream: potential")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
     args = ap.parse_args()
     if args.workload == "c3":

@@ -1,0 +1,227 @@
+// kernels_sepn.hip -- harmonic / diagonal-Gaussian potentials, 16 < D <= 256, Leapfrog in the
+// PBBI_KDK_FMA form: a chain's dimensions are cut into 16-dim PARTS held by different WAVES of one
+// workgroup, gfx950.
+//
+// With one chain per lane (kernels_lane.hip) a D = 64 chain needs 192 VGPRs of state and runs one
+// wave per SIMD at 24 % of the HBM roofline; D = 128 does not fit at all.  A separable potential has
+// no coupling between dimensions: workgroup b owns chains 64b .. 64b+63, its wave w the dims
+// 16w .. 16w+15 of all of them.  The part index is wave-uniform, so the part's means and precisions
+// sit in SGPRs (scalar loads), the per-lane state is x = q - mu and the velocity only (64 VGPRs),
+// and every load / store is a full 512-byte row segment.  The parts meet once per iteration: each
+// wave's share of oldH - newH goes through LDS, one __syncthreads, and every wave takes the same
+// accept decision.
+//
+// Kick-drift-kick with fused multiply-adds (include/pbbi.h, PBBI_KDK_FMA): per element-step
+//     x = fma(v, h, x);  v = fma(prec*x, -h/m, v)     (x = q - mu)      -- 3 fp64 instructions,
+// so the kernel is bound by HBM (4*D*8 B per chain per iteration), not by the vector ALU.
+// Algebraically src/integrator.py:105-120; agrees with the oracle to ~1e-13 relative, accept masks
+// equal (tests/test_gpu_parity.py::test_separable_multilane_kdk).  The bit-exact reference-order
+// kernels stay the default; this path is taken only when the caller passes PBBI_KDK_FMA.
+#include "pbbi_buf.h"
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+constexpr int DL = 16;      // dims per wave
+constexpr int MAXG = 16;    // waves per workgroup (D <= 256)
+
+struct SepPrm {
+    const double* q_in;
+    const double* p_in;
+    const double* u_in;
+    const double* mass;
+    double* q_out;
+    double* p_out;
+    double* ratio_out;
+    uint8_t* reject_out;
+    const double* mean;  // D
+    const double* prec;  // D (spring constants for the harmonic potential)
+    int64_t N, ldn_in, ldn_out;
+    double h, cst, kT;
+    int L, D, flags, rng;
+    uint64_t seed, iter, chain0;
+};
+
+// FULL: D is a multiple of 16, every dim of every part exists: no guards (as scalar branches they
+// put an s_waitcnt between consecutive loads / stores)
+// Stores of dims past D (last part when D is not a multiple of 16) go here instead of being
+// branched around: a scalar branch per row puts an s_waitcnt between consecutive memory
+// instructions (measured at D = 100: 0.41 of the HBM roofline with branches, vs 0.8-0.9 at D = 128).
+__device__ double g_sink[64];
+
+template <bool UNIT, bool FULL>
+__global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
+    __shared__ double dH[MAXG][64];
+    const int c = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
+    const int G = (int)(blockDim.x >> 6);
+    const int64_t n0 = (int64_t)blockIdx.x * 64;  // block-uniform
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;
+    const int D = prm.D;
+    const int d0 = DL * part;
+    const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
+    const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vo = 8u * (uint32_t)cc;
+    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in);
+    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out);
+    auto exists = [&](int j) { return FULL || d0 + j < D; };  // wave-uniform
+    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_sink);
+    // row j of an input array, clamped to an existing row (the value is discarded by a select)
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) {
+        return buf_load<double>(r, vo, exists(j) ? (uint32_t)j * rin : 0u);
+    };
+    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) {
+        if constexpr (FULL) buf_store(r, vo, (uint32_t)j * rout, x);
+        else buf_store(exists(j) ? r : bsink, vo, exists(j) ? (uint32_t)j * rout : 0u, x);
+    };
+
+    // this part's constants (SGPRs); a dim past D gets prec = 0 and stays at x = v = 0
+    double mu[DL], pr[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        const int d = exists(j) ? d0 + j : D - 1;
+        mu[j] = prm.mean[d];
+        pr[j] = exists(j) ? prm.prec[d] : 0.0;
+    }
+    const double h = prm.h, nhm = UNIT ? -h : -(h / m), nhh = 0.5 * nhm;
+    double q[DL], v[DL];  // q holds x = q - mu between the load and the store
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        const double x = ld(bq, j) - mu[j];
+        q[j] = exists(j) ? x : 0.0;
+    }
+    const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    auto draw = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // this part's group of 16 dims: blocks (part<<2)|r
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+        }
+    };
+    auto load_p = [&]() {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double x = ld(bp, j);
+            v[j] = exists(j) ? x : 0.0;
+        }
+    };
+    if (prm.rng) draw(); else load_p();
+
+    // this part's share of H = 0.5 p.p / m + 0.5 sum prec x^2 (+ cst, which cancels in oldH - newH)
+    auto energy = [&]() {
+        double pp = 0.0, xx = 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            pp = fma(v[j], v[j], pp);
+            xx = fma(pr[j] * q[j], q[j], xx);
+        }
+        return 0.5 * pp / m + 0.5 * xx;
+    };
+    const double oldE = energy();
+
+    // ---- Leapfrog, kick-drift-kick: vh = v + a0 h/2;  L x { x += vh h; vh += a(x) h }, last kick half
+    // a = -prec x / m:  vh = fma(prec x, -h/m, vh)
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
+    }
+    if (prm.L > 0) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = fma(pr[j] * q[j], nhh, v[j]);
+        for (int s = 0; s + 1 < prm.L; ++s) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                q[j] = fma(v[j], h, q[j]);
+                v[j] = fma(pr[j] * q[j], nhm, v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            q[j] = fma(v[j], h, q[j]);
+            v[j] = fma(pr[j] * q[j], nhh, v[j]);
+        }
+    }
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+
+    // oldH - newH: the parts' shares summed in part order (the same value in every wave)
+    dH[part][c] = oldE - energy();
+    __syncthreads();
+    double dsum = 0.0;
+    for (int g = 0; g < G; ++g) dsum += dH[g][c];
+    const double ratio = exp(dsum);  // src/HMC.py:115
+    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    // back to positions: q = x + mu, or the untouched old position for a rejected chain (:175)
+#pragma unroll
+    for (int j = 0; j < DL; ++j) q[j] = q[j] + mu[j];
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] = ld(bq, j);
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < DL; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+                load_p();
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) st(bqo, j, q[j]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) st(bpo, j, v[j]);
+        }
+        if (part == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace
+
+// true if this path takes the call: harmonic / diagonal Gaussian, fp64, Leapfrog, 16 < D <= 256,
+// and the caller allowed the kick-drift-kick/FMA form
+bool sepn_applies(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    return (pot->kind == KIND_HARMONIC || pot->kind == KIND_GAUSS_DIAG) && pot->dtype == PBBI_F64 &&
+           a.method == PBBI_LEAPFROG && (a.flags & PBBI_KDK_FMA) != 0 && pot->D > 16 &&
+           pot->D <= DL * MAXG &&
+           (int64_t)DL * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
+}
+
+int sepn_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (a.N == 0) return PBBI_OK;
+    SepPrm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+               (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
+               a.reject_out, (const double*)pot->d_mean, (const double*)pot->d_prec, a.N, a.ldn_in,
+               a.ldn_out, a.h, pot->cst, a.kT, a.L, pot->D, a.flags, a.rng, a.seed, a.iter, a.chain0};
+    const int G = (pot->D + DL - 1) / DL;
+    const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
+    const bool full = (pot->D % DL == 0);
+    if (a.mass) {
+        if (full) hipLaunchKernelGGL((k_sep_hmc<false, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_sep_hmc<false, false>), grid, block, 0, a.stream, prm);
+    } else {
+        if (full) hipLaunchKernelGGL((k_sep_hmc<true, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_sep_hmc<true, false>), grid, block, 0, a.stream, prm);
+    }
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}

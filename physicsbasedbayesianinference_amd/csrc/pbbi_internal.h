@@ -122,6 +122,9 @@ int lane_energy(const EvalArgs& a);
 // Rosenbrock 16 < D <= 32, Leapfrog: two lanes per chain (config C3), kernels_lane2.hip
 bool lane2_applies(const IterArgs& a);
 int lane2_hmc_iter(const IterArgs& a);
+// harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
+bool sepn_applies(const IterArgs& a);
+int sepn_hmc_iter(const IterArgs& a);
 // the same potentials for D > 64 and for fp32: chain state in a device workspace, kernels_stream.hip
 int stream_hmc_iter(const IterArgs& a);
 int stream_integrate(const IntegrateArgs& a);

@@ -1054,3 +1054,49 @@ def test_rosenbrock_kdk_fma_form(P, lib, D, N, mass):
         q = samples[:, :, i].copy()  # continue from the device state: compare step by step
         n_rej += int(rej.sum())
     assert n_rej > 0
+
+
+@pytest.mark.parametrize("kind,D,N,mass", [("diag", 32, 700, False), ("harmonic", 17, 100, True),
+                                           ("diag", 64, 333, True), ("diag", 50, 64, False),
+                                           ("harmonic", 128, 1000, False), ("diag", 100, 257, True),
+                                           ("diag", 256, 130, False), ("harmonic", 241, 70, True)])
+def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
+    """kernels_sepn.hip: harmonic / diagonal Gaussian, a chain's 16-dim parts in different waves of
+    one workgroup, PBBI_KDK_FMA form (both RNG modes): q, p within 1e-12 of the oracle's
+    velocity-Verlet, masks equal."""
+    rs = np.random.RandomState(D + N)
+    pot, op = _stream_case(P, kind, D, rs)
+    S, L, h, seed = 4, 7, 0.45, 21
+    m = (1.0 + (np.arange(N) % 4) * 0.5) if mass else None
+    ens = P.Ensemble(D, N)
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=True,
+                compat=False, verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 1.0, chain0=9)
+    q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 9, D, N, 1.0)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 9, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, i, 9, N)
+        r_or, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=0)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
+        assert np.max(np.abs(np.log(hmc.ratios[i]) - np.log(r_or))) < 1e-9
+        q = samples[:, :, i].copy()
+        n_rej += int(rej.sum())
+    assert 0 < n_rej < S * N
+    # host-supplied momenta / uniforms through pbbi_hmc_iter with the flag
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    p, u = rs.standard_normal((D, N)) * pstd, rs.uniform(size=N)
+    qd, pd, ud = (as_device(x, 0, np.float64) for x in (q, p, u))
+    md = as_device(m, 0, np.float64) if mass else None
+    qo, po, rj = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0), empty((N,), np.uint8, 0)
+    lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+             md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), None, rj.data_ptr(), N, N, h, L,
+             lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA, stream_ptr(0))
+    q_or, p_or = q.copy(), p.copy()
+    _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L)
+    assert np.array_equal(to_numpy(rj).astype(bool), rej)
+    assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
