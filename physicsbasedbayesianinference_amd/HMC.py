@@ -20,6 +20,12 @@ rejected chains record their OLD POSITION as momentum (src/HMC.py:176); momenta 
 stored un-negated (:164,:179); a NaN ratio is accepted (:168-173); the accept test
 uses beta = 1 whatever `temperature` is (:115).  `compat=False` only changes the
 first: a rejected chain then records the momentum it drew.
+
+`kdk_fma=True` (opt-in, Leapfrog only) passes PBBI_KDK_FMA (include/pbbi.h): kernels that honour it
+integrate in kick-drift-kick form with fused multiply-adds -- the same integrator algebraically,
+trajectories within ~1e-13 of the reference's operation order instead of bit-identical, accept
+masks as before -- which turns the elementwise-potential kernels from instruction-bound into
+HBM-bound.  The default keeps the reference's operation order.
 """
 import numpy as np
 from scipy.constants import Boltzmann as boltzmannConst
