@@ -125,6 +125,9 @@ int lane2_hmc_iter(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
 bool sepn_applies(const IterArgs& a);
 int sepn_hmc_iter(const IterArgs& a);
+// Rosenbrock, 32 < D <= 256, PBBI_KDK_FMA, same layout with boundary exchange through LDS, kernels_rosn.hip
+bool rosn_applies(const IterArgs& a);
+int rosn_hmc_iter(const IterArgs& a);
 // the same potentials for D > 64 and for fp32: chain state in a device workspace, kernels_stream.hip
 int stream_hmc_iter(const IterArgs& a);
 int stream_integrate(const IntegrateArgs& a);

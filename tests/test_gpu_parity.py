@@ -1100,3 +1100,49 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
     _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L)
     assert np.array_equal(to_numpy(rj).astype(bool), rej)
     assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
+
+
+@pytest.mark.parametrize("D,N,mass", [(48, 500, False), (64, 333, True), (100, 130, False),
+                                      (128, 1000, False), (256, 70, True), (33, 64, False)])
+def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
+    """kernels_rosn.hip: Rosenbrock at 32 < D <= 256 with a chain's 16-dim parts in different waves
+    (boundary values exchanged through LDS), PBBI_KDK_FMA form: q, p within 1e-12 of the oracle's
+    velocity-Verlet, accept masks equal, both RNG modes."""
+    S, L, h, seed = 4, 8, 0.03, 31
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    m = (1.0 + (np.arange(N) % 3) * 0.5) if mass else None
+    ens = P.Ensemble(D, N)
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=True,
+                verbose=False)
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=3)
+    q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 3, D, N, 0.3)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 3, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, i, 3, N)
+        r_or, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
+        fin = np.isfinite(r_or) & (r_or > 0)
+        assert np.max(np.abs(np.log(hmc.ratios[i][fin]) - np.log(r_or[fin]))) < 1e-9
+        q = samples[:, :, i].copy()
+        n_rej += int(rej.sum())
+    assert 0 < n_rej < S * N
+    # host-supplied momenta / uniforms, zero steps and one step
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D)
+    for Lx in (0, 1):
+        p, u = rs.standard_normal((D, N)) * pstd, rs.uniform(size=N)
+        qd, pd, ud = (as_device(x, 0, np.float64) for x in (q, p, u))
+        md = as_device(m, 0, np.float64) if mass else None
+        qo, po, rj = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0), empty((N,), np.uint8, 0)
+        lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+                 md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), None, rj.data_ptr(), N, N,
+                 h, Lx, lib.KDK_FMA, stream_ptr(0))
+        q_or, p_or = q.copy(), p.copy()
+        _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, Lx, compat=0)
+        assert np.array_equal(to_numpy(rj).astype(bool), rej)
+        assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
