@@ -21,11 +21,12 @@ stored un-negated (:164,:179); a NaN ratio is accepted (:168-173); the accept te
 uses beta = 1 whatever `temperature` is (:115).  `compat=False` only changes the
 first: a rejected chain then records the momentum it drew.
 
-`kdk_fma=True` (opt-in, Leapfrog only) passes PBBI_KDK_FMA (include/pbbi.h): kernels that honour it
+`kdk_fma` (Leapfrog only; default: True for rng="philox", False for rng="numpy") passes
+PBBI_KDK_FMA (include/pbbi.h): kernels that honour it
 integrate in kick-drift-kick form with fused multiply-adds -- the same integrator algebraically,
 trajectories within ~1e-13 of the reference's operation order instead of bit-identical, accept
 masks as before -- which turns the elementwise-potential kernels from instruction-bound into
-HBM-bound.  The default keeps the reference's operation order.
+HBM-bound.  kdk_fma=False keeps the reference's operation order everywhere.
 """
 import numpy as np
 from scipy.constants import Boltzmann as boltzmannConst
@@ -39,13 +40,15 @@ __all__ = ["HMC"]
 
 class HMC:
     def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
-                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=False):
+                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=None):
         self.ensemble = ensemble
         self.simulTime = simulTime
         self.stepSize = stepSize
         self.density = density
         self.compat = bool(compat)
-        self.kdk_fma = bool(kdk_fma)  # PBBI_KDK_FMA: throughput form of Leapfrog (include/pbbi.h)
+        # PBBI_KDK_FMA, the throughput form of Leapfrog (include/pbbi.h): default on in the
+        # throughput RNG mode, off in the reference-parity mode
+        self.kdk_fma = (rng == "philox") if kdk_fma is None else bool(kdk_fma)
         self.rng = rng
         self.seed = int(seed)
         self.verbose = verbose

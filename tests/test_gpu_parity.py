@@ -360,7 +360,7 @@ def test_hmc_run_philox_vs_oracle(P, lib, kind, D, N, method, mass):
         ens.mass = m.copy()
     seed, chain0, iter0, kT = 2024, 1000, 7, 1.0
     hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, method=method, rng="philox", seed=seed,
-                verbose=False)
+                kdk_fma=False, verbose=False)  # reference operation order: exact comparison below
     assert hmc.integrator.numSteps == L
     samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.7, chain0=chain0, iter0=iter0)
     q = device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 0.7)
@@ -811,7 +811,8 @@ def test_streaming_lane_path_philox_and_fp32(P, lib):
     pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
     ens = P.Ensemble(D, N)
     seed, chain0, iter0 = 11, 5, 2
-    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, verbose=False)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=False,
+                verbose=False)
     samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=chain0, iter0=iter0)
     q = device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 0.3)
     for i in range(S):
@@ -984,7 +985,7 @@ def test_rosenbrock_run_with_many_rejections_bitexact(P, lib, D, N, mass, compat
     if mass:
         ens.mass = m.copy()
     hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, compat=compat,
-                verbose=False)
+                kdk_fma=False, verbose=False)
     samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=chain0, iter0=iter0)
     q = 0.0 + device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 0.3)
     pstd = np.sqrt(m) if mass else np.ones(N)
