@@ -362,6 +362,173 @@ __global__ void __launch_bounds__(SB) k_custom_eval(EvalPrm prm) {
     }
 }
 
+
+// ---- register-resident variant ----------------------------------------------------------------
+// custom.py compiles the plugin for ONE dimension (-DPBBI_D=<D>).  When the chain fits a lane's
+// registers (q, v, a, g: 4*D values) the user's functions are called on register arrays: their
+// loops over D have a constant trip count after inlining, unroll, and index the arrays with
+// constants -- the same shape as kernels_lane.hip (one chain per lane, state on chip for all L
+// steps, HBM touched once on the way in and once on the way out), at the same operation order.
+#if defined(PBBI_D)
+constexpr int REG_DMAX = sizeof(T) == 8 ? 16 : 32;
+constexpr bool REG_OK = (PBBI_D) <= REG_DMAX;
+constexpr int RD = REG_OK ? (PBBI_D) : 1;
+#else
+constexpr bool REG_OK = false;
+constexpr int RD = 1;
+#endif
+constexpr int RB = 256;  // chains per workgroup
+
+struct Vec {
+    T x[RD];
+    __device__ __forceinline__ T& operator[](int j) { return x[j]; }
+    __device__ __forceinline__ const T& operator[](int j) const { return x[j]; }
+};
+
+template <int METHOD, bool UNIT>
+__device__ __forceinline__ void reg_trajectory(Vec& q, Vec& v, const T* prm, T m, T h, int L) {
+    const T h2 = h * h, half = T(0.5), hh = half * h, hh2 = half * h2;
+    Vec a, g;
+    if constexpr (METHOD == PBBI_LEAPFROG) {
+        user::gradient(q, g, RD, prm);
+#pragma unroll
+        for (int j = 0; j < RD; ++j) a[j] = UNIT ? -g[j] : -g[j] / m;  // src/integrator.py:73,108
+        for (int s = 0; s < L; ++s) {
+#pragma unroll
+            for (int j = 0; j < RD; ++j) q[j] += (v[j] * h + a[j] * hh2);  // :112-115
+            user::gradient(q, g, RD, prm);
+#pragma unroll
+            for (int j = 0; j < RD; ++j) {  // :116-118
+                const T an = UNIT ? -g[j] : -g[j] / m;
+                v[j] += (a[j] + an) * hh;
+                a[j] = an;
+            }
+        }
+    } else {
+        Vec qpast = q;  // :147
+        user::gradient(q, g, RD, prm);
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+            const T aj = UNIT ? -g[j] : -g[j] / m;
+            q[j] = (q[j] + v[j] * h) + (half * aj) * h2;  // :148-150
+        }
+        for (int s = 0; s < L; ++s) {
+            user::gradient(q, g, RD, prm);
+#pragma unroll
+            for (int j = 0; j < RD; ++j) {  // :152-158
+                const T aj = UNIT ? -g[j] : -g[j] / m;
+                const T cur = q[j];
+                q[j] = (T(2) * cur - qpast[j]) + aj * h2;
+                qpast[j] = cur;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = (q[j] - qpast[j]) / h;  // :160
+    }
+}
+
+template <int METHOD, bool UNIT>
+__global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
+    const int64_t n = (int64_t)blockIdx.x * RB + threadIdx.x;
+    if (n >= prm.N) return;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    const uint64_t chain = prm.chain0 + (uint64_t)n;
+    const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
+    const T* qin = prm.q_in + n;
+    const T* pin = prm.rng ? nullptr : prm.p_in + n;
+    Vec q, v;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) q[j] = qin[(int64_t)j * prm.ldn_in];
+    auto draw = [&]() {
+#pragma unroll
+        for (int G = 0; G < (RD + 15) / 16; ++G)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * G + r < RD) {
+                    float z[4];
+                    rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((G << 2) | r), z);
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int d = 16 * G + r + 4 * sl;
+                        if (d < RD) v[d] = (T)((double)z[sl] * pstd);
+                    }
+                }
+            }
+    };
+    T u;
+    if (prm.rng) {
+        draw();
+        u = (T)rng_uniform(prm.seed, prm.iter, chain);
+    } else {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = pin[(int64_t)j * prm.ldn_in];
+        u = prm.u_in[n];
+    }
+    T pp = T(0);
+#pragma unroll
+    for (int j = 0; j < RD; ++j) pp += v[j] * v[j];
+    const T oldH = T(0.5) * pp / m + user::potential(q, RD, prm.prm);  // src/HMC.py:100-102
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = v[j] / m;
+    }
+    reg_trajectory<METHOD, UNIT>(q, v, prm.prm, m, prm.h, prm.L);
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+    T pp1 = T(0);
+#pragma unroll
+    for (int j = 0; j < RD; ++j) pp1 += v[j] * v[j];
+    const T newH = T(0.5) * pp1 / m + user::potential(q, RD, prm.prm);
+    const T ratio = exp(oldH - newH);  // src/HMC.py:115
+    const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) q[j] = qin[(int64_t)j * prm.ldn_in];  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < RD; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+#pragma unroll
+                for (int j = 0; j < RD; ++j) v[j] = pin[(int64_t)j * prm.ldn_in];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RD; ++j) prm.q_out[(int64_t)j * prm.ldn_out + n] = q[j];
+    if (prm.p_out) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) prm.p_out[(int64_t)j * prm.ldn_out + n] = v[j];
+    }
+    if (prm.ratio_out) prm.ratio_out[n] = ratio;
+    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+}
+
+template <int METHOD, bool UNIT>
+__global__ void __launch_bounds__(RB) k_custom_reg_integrate(IntPrm prm) {
+    const int64_t n = (int64_t)blockIdx.x * RB + threadIdx.x;
+    if (n >= prm.N) return;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    Vec q, v;
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        q[j] = prm.q[(int64_t)j * prm.ldn + n];
+        const T p = prm.p[(int64_t)j * prm.ldn + n];
+        v[j] = UNIT ? p : p / m;
+    }
+    reg_trajectory<METHOD, UNIT>(q, v, prm.prm, m, prm.h, prm.L);
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        prm.q[(int64_t)j * prm.ldn + n] = q[j];
+        prm.p[(int64_t)j * prm.ldn + n] = UNIT ? v[j] : v[j] * m;
+        if (prm.v_out) prm.v_out[(int64_t)j * prm.ldn + n] = v[j];
+    }
+}
+
 struct Workspace {  // stream-ordered scratch for one call
     hipStream_t st;
     std::vector<void*> ptrs;
@@ -390,6 +557,42 @@ void with_method_unit(int method, bool unit, F&& f) {
     }
 }
 
+// launchers of the register-resident kernels; templates so that a plugin whose D does not fit
+// never instantiates them (nor the user's functions on a one-element array)
+template <bool R>
+int reg_hmc(const IterArgs* a) {
+    if constexpr (R) {
+        const pbbi_potential* pot = a->pot;
+        HmcPrm prm{(const T*)a->q_in, (const T*)a->p_in, (const T*)a->u_in, (const T*)a->mass,
+                   (T*)a->q_out, (T*)a->p_out, (T*)a->ratio_out, a->reject_out,
+                   a->N, a->ldn_in, a->ldn_out, (T)a->h, a->L, pot->D, a->flags, a->rng,
+                   a->seed, a->iter, a->chain0, a->kT, (const T*)pot->d_params, nullptr, nullptr,
+                   nullptr, nullptr};
+        with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+            hipLaunchKernelGGL((k_custom_reg_hmc<decltype(meth)::value, decltype(unit)::value>),
+                               dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
+        });
+        return (int)hipGetLastError();
+    } else {
+        return -1;
+    }
+}
+template <bool R>
+int reg_integrate(const IntegrateArgs* a) {
+    if constexpr (R) {
+        const pbbi_potential* pot = a->pot;
+        IntPrm prm{(T*)a->q, (T*)a->p, (const T*)a->mass, (T*)a->v_out, a->N, a->ldn, (T)a->h, a->L,
+                   pot->D, (const T*)pot->d_params, nullptr, nullptr, nullptr, nullptr};
+        with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+            hipLaunchKernelGGL((k_custom_reg_integrate<decltype(meth)::value, decltype(unit)::value>),
+                               dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
+        });
+        return (int)hipGetLastError();
+    } else {
+        return -1;
+    }
+}
+
 }  // namespace pbbi_custom
 
 // ---- the plugin's exported surface (resolved by pbbi_potential_create_custom) -----------------
@@ -402,6 +605,7 @@ int pbbi_plugin_dtype(void) { return sizeof(T) == 8 ? PBBI_F64 : PBBI_F32; }
 int pbbi_plugin_hmc_iter(const IterArgs* a) {
     using namespace pbbi_custom;
     const pbbi_potential* pot = a->pot;
+    if (REG_OK && pot->D == RD) return reg_hmc<REG_OK>(a);  // the chain fits the lane's registers
     Workspace ws(a->stream);
     const size_t slab = (size_t)pot->D * a->N;
     T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);
@@ -420,6 +624,7 @@ int pbbi_plugin_hmc_iter(const IterArgs* a) {
 int pbbi_plugin_integrate(const IntegrateArgs* a) {
     using namespace pbbi_custom;
     const pbbi_potential* pot = a->pot;
+    if (REG_OK && pot->D == RD) return reg_integrate<REG_OK>(a);
     Workspace ws(a->stream);
     const size_t slab = (size_t)pot->D * a->N;
     T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);

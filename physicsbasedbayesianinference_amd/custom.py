@@ -50,10 +50,12 @@ _CACHE = os.path.join(_HERE, "_plugins")
 _DEPS = ("pbbi_custom.h", "pbbi_internal.h", "pbbi_rng.h")
 
 
-def plugin_source(source, dtype="float64"):
-    """The translation unit hipcc sees for one user source."""
+def plugin_source(source, dtype="float64", D=None):
+    """The translation unit hipcc sees for one user source (and one dimension: PBBI_D lets small
+    chains run from registers, csrc/pbbi_custom.h)."""
     ctype = {"float64": "double", "float32": "float"}[str(np.dtype(dtype))]
-    return ('#include <hip/hip_runtime.h>\n#include <type_traits>\n'
+    return ((f'#define PBBI_D {int(D)}\n' if D else '') +
+            '#include <hip/hip_runtime.h>\n#include <type_traits>\n'
             '#include "pbbi_internal.h"\n#include "pbbi_rng.h"\n'
             f'using T = {ctype};\n#define PBBI_FN __device__ __forceinline__\n'
             'namespace user {\n' + source + '\n}  // namespace user\n'
@@ -68,10 +70,10 @@ def _hipcc():
                        "gfx950 at construction and there is no CPU fallback")
 
 
-def compile_plugin(source, dtype="float64", verbose=False):
+def compile_plugin(source, dtype="float64", verbose=False, D=None):
     """Build (or find in the in-tree cache) the plugin .so of a user source; needs hipcc, not a
-    GPU.  The cache key covers the source, the dtype and the kernel headers."""
-    tu = plugin_source(source, dtype)
+    GPU.  The cache key covers the source, the dtype, the dimension and the kernel headers."""
+    tu = plugin_source(source, dtype, D)
     h = hashlib.sha256(tu.encode())
     for dep in _DEPS:
         with open(os.path.join(_CSRC, dep), "rb") as f:
@@ -107,7 +109,7 @@ class CustomPotential(Potential):
         super().__init__(D, dtype, device)
         self.source = source
         self.params = np.ascontiguousarray(params, dtype=np.float64).ravel()
-        self.plugin_path = compile_plugin(source, self.dtype, verbose=verbose)
+        self.plugin_path = compile_plugin(source, self.dtype, verbose=verbose, D=int(D))
         _lib.call("pbbi_potential_create_custom", self.plugin_path.encode(), int(D),
                   _dptr(self.params) if self.params.size else None, int(self.params.size),
                   self._dt, self.device, C.byref(self._handle))

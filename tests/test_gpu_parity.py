@@ -839,13 +839,14 @@ def test_streaming_lane_path_philox_and_fp32(P, lib):
 
 
 # ------------------------------------------------------------------ user-defined potentials
+@pytest.mark.parametrize("D", [11, 40])  # 11: register-resident plugin kernels; 40: workspace kernels
 @pytest.mark.parametrize("method,mass", [("Leapfrog", False), ("Leapfrog", True), ("Stormer-Verlet", True)])
-def test_custom_potential_polynomial_bit_exact(P, lib, method, mass):
+def test_custom_potential_polynomial_bit_exact(P, lib, method, mass, D):
     """CustomPotential: the user's C++ source inlined into the plugin kernels vs the same source
     compiled for the host inside the oracle.  Polynomial potential => bit-identical."""
     from custom_sources import QUARTIC
     from physicsbasedbayesianinference_amd.custom import CustomPotential
-    D, N, L, h = 11, 300, 9, 0.07
+    N, L, h = 300, 9, 0.07
     prm = [1.5, 0.75]
     pot, op = CustomPotential(D, QUARTIC, prm), orc.pot_custom(QUARTIC, D, prm)
     rs = np.random.RandomState(5)

@@ -202,14 +202,17 @@ def test_custom_potential_plugin_builds_and_exports():
     import subprocess
     from physicsbasedbayesianinference_amd.custom import compile_plugin
     from custom_sources import COIN_TOSS_SOURCE, LOGISTIC, QUARTIC
-    for src, dtype in ((QUARTIC, "float64"), (LOGISTIC, "float64"), (QUARTIC, "float32"),
-                       (COIN_TOSS_SOURCE, "float64")):
-        so = compile_plugin(src, dtype)
+    # (source, dtype, D): the dimensions the GPU parity tests construct (D <= 16 in fp64 / 32 in fp32
+    # compile the register-resident kernels as well), and one build without a fixed dimension
+    for src, dtype, D in ((QUARTIC, "float64", 11), (QUARTIC, "float64", 40), (LOGISTIC, "float64", 5),
+                          (QUARTIC, "float32", 7), (COIN_TOSS_SOURCE, "float64", 1),
+                          (QUARTIC, "float64", None)):
+        so = compile_plugin(src, dtype, D=D)
         syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
         for name in ("pbbi_plugin_abi", "pbbi_plugin_dtype", "pbbi_plugin_hmc_iter",
                      "pbbi_plugin_integrate", "pbbi_plugin_eval"):
             assert f" T {name}" in syms, name
-        assert compile_plugin(src, dtype) == so  # cache hit
+        assert compile_plugin(src, dtype, D=D) == so  # cache hit
     with pytest.raises(RuntimeError, match="hipcc failed"):
         compile_plugin("this is not C++")
 

@@ -40,7 +40,8 @@ def run(name, pot, D, N, h, L=10, K=10, W=2):
 
 
 if __name__ == "__main__":
-    run("quartic chain", CustomPotential(32, QUARTIC, [1.0, 0.5]), 32, 262144, 0.05)
+    run("quartic chain (registers)", CustomPotential(16, QUARTIC, [1.0, 0.5]), 16, 262144, 0.05)
+    run("quartic chain (workspace)", CustomPotential(32, QUARTIC, [1.0, 0.5]), 32, 262144, 0.05)
     run("quartic chain", CustomPotential(128, QUARTIC, [1.0, 0.5]), 128, 65536, 0.05)
     X, y, lam, prm = logistic_problem(M=256, D=16)
     run("logistic regression M=256", CustomPotential(16, LOGISTIC, prm), 16, 65536, 0.02)
