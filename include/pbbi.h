@@ -215,6 +215,13 @@ int pbbi_transpose_sdn_to_dns(const void* src_sdn, void* dst_dns, int S, int D, 
 int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
                         void* mean_out, void* var_out, void* stream);
 
+/* Per-CHAIN mean and unbiased variance over the S draws of each (dim, chain): chain_mean_out and
+ * chain_var_out are (D, N) device arrays (stride N) in the slabs' dtype, accumulated in fp64
+ * (Welford).  The ingredients of the Gelman-Rubin statistic across the ensemble's chains
+ * (HMC.rhat in the Python layer); S >= 2. */
+int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                       void* chain_mean_out, void* chain_var_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

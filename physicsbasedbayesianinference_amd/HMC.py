@@ -327,6 +327,34 @@ class HMC:
                   mean.data_ptr(), var.data_ptr(), stream_ptr(pot.device))
         return to_numpy(mean).astype(np.float64), to_numpy(var).astype(np.float64)
 
+    def rhat(self, samples_dns):
+        """Gelman-Rubin potential scale reduction per dimension, across the ensemble's N chains,
+        from the (D, N, S) device view of getSamples(device_output=True) / sampleChunks -- computed
+        on the GPU (per-chain Welford moments, then the ensemble moments of those): with
+        W = mean_n var_s, B/S = var_n mean_s,  R = sqrt(((S-1)/S W + B/S) / W).  Values near 1 say
+        the chains agree; the ensemble design makes this the natural convergence check
+        (SURVEY 8f row 4).  Returns a float64 array of D values."""
+        pot = self._pot
+        sdn = samples_dns.permute(2, 0, 1)
+        if not sdn.is_contiguous():
+            sdn = sdn.contiguous()
+        S, D, N = sdn.shape
+        if S < 2 or N < 2:
+            raise ValueError("rhat needs at least 2 draws and 2 chains")
+        cm, cv = empty((1, D, N), pot.dtype, pot.device), empty((1, D, N), pot.dtype, pot.device)
+        stream = stream_ptr(pot.device)
+        _lib.call("pbbi_chain_moments", sdn.data_ptr(), S, D, N, pot._dt, pot.device, cm.data_ptr(),
+                  cv.data_ptr(), stream)
+        w = empty((D,), pot.dtype, pot.device)
+        bvar = empty((D,), pot.dtype, pot.device)
+        _lib.call("pbbi_sample_moments", cv.data_ptr(), 1, D, N, pot._dt, pot.device, w.data_ptr(), None,
+                  stream)                                     # W = mean over chains of the chain variances
+        _lib.call("pbbi_sample_moments", cm.data_ptr(), 1, D, N, pot._dt, pot.device, None,
+                  bvar.data_ptr(), stream)                    # biased variance over chains of the chain means
+        W = to_numpy(w).astype(np.float64)
+        B_over_S = to_numpy(bvar).astype(np.float64) * N / (N - 1.0)
+        return np.sqrt(((S - 1.0) / S * W + B_over_S) / W)
+
     def _to_dns(self, sdn):
         """(S, D, N) device slabs -> host (D, N, S) array via the LDS-tiled transpose kernel."""
         pot = self._pot

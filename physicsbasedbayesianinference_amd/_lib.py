@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pbbi_philox_uniform": [_u64, _u64, _u64, _i64, _i, _i, _vp, _vp],
     "pbbi_transpose_sdn_to_dns": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "pbbi_sample_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
+    "pbbi_chain_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -206,6 +206,24 @@ __global__ void k_moments_final(const double* __restrict__ part, int D, int chun
     if (var_out) var_out[d] = (T)(s2 / count - mean * mean);
 }
 
+// per-(dim, chain) mean and unbiased variance over the S slabs; lanes run along the chain axis
+template <typename T>
+__global__ void k_chain_moments(const T* __restrict__ x, int S, int D, int64_t N, T* mean_out,
+                                T* var_out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (n >= N) return;
+    double mean = 0.0, m2 = 0.0;
+    for (int s = 0; s < S; ++s) {  // Welford
+        const double v = (double)x[((int64_t)s * D + d) * N + n];
+        const double delta = v - mean;
+        mean += delta / (double)(s + 1);
+        m2 += delta * (v - mean);
+    }
+    if (mean_out) mean_out[(int64_t)d * N + n] = (T)mean;
+    if (var_out) var_out[(int64_t)d * N + n] = (T)(m2 / (double)(S - 1));
+}
+
 }  // namespace
 
 // ======================================================================= library
@@ -538,6 +556,25 @@ int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dt
     }
     PBBI_HIP(hipGetLastError());
     PBBI_HIP(hipFreeAsync(part, (hipStream_t)stream));
+    return PBBI_OK;
+}
+
+int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                       void* chain_mean_out, void* chain_var_out, void* stream) {
+    if (S < 2 || D < 1 || N < 1) return pbbi_fail(PBBI_ERR_INVALID, "need S >= 2, D >= 1, N >= 1");
+    if (!samples_sdn) return pbbi_fail(PBBI_ERR_INVALID, "samples is NULL");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    DeviceGuard guard(device);
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)D), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_chain_moments<double>, grid, block, 0, (hipStream_t)stream,
+                           (const double*)samples_sdn, S, D, N, (double*)chain_mean_out,
+                           (double*)chain_var_out);
+    else
+        hipLaunchKernelGGL(k_chain_moments<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float*)samples_sdn, S, D, N, (float*)chain_mean_out,
+                           (float*)chain_var_out);
+    PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
 

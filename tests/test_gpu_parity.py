@@ -1196,3 +1196,26 @@ def test_hmc_iter_in_place_aliasing(P, lib, case):
     torch.cuda.synchronize()
     assert np.array_equal(to_numpy(rj1), to_numpy(rj2)) and 0 < to_numpy(rj1).sum() < N
     assert np.array_equal(to_numpy(qo), to_numpy(qd)) and np.array_equal(to_numpy(po), to_numpy(pd))
+
+
+def test_rhat_matches_numpy_and_detects_disagreement(P):
+    """HMC.rhat (per-chain Welford moments + ensemble moments on the GPU) == the NumPy formula on the
+    same draws; ~1 for a converged ensemble, large when half the chains sit elsewhere."""
+    import torch
+    D, N, S = 6, 512, 40
+    pot = P.GaussianDiag(np.zeros(D), prec=np.ones(D), const=0.0)
+    hmc = P.HMC(P.Ensemble(D, N), 1.3, 0.1, None, potential=pot, rng="philox", seed=3, verbose=False)
+    s_dev, _ = hmc.getSamples(S, 1 / kB, 1.0, device_output=True)
+
+    def rhat_np(x):                      # x: (D, N, S)
+        m, v = x.mean(axis=2), x.var(axis=2, ddof=1)
+        W, B_over_S = v.mean(axis=1), m.var(axis=1, ddof=1)
+        return np.sqrt(((S - 1.0) / S * W + B_over_S) / W)
+    r = hmc.rhat(s_dev)
+    assert np.allclose(r, rhat_np(s_dev.cpu().numpy()), rtol=1e-10)
+    assert np.all(np.abs(r - 1.0) < 0.05)
+    shifted = s_dev.clone()
+    shifted[0, : N // 2, :] += 5.0
+    r2 = hmc.rhat(shifted)
+    assert np.allclose(r2, rhat_np(shifted.cpu().numpy()), rtol=1e-10)
+    assert r2[0] > 2.0 and np.all(np.abs(r2[1:] - 1.0) < 0.05)
