@@ -30,31 +30,34 @@ struct SeparablePot {  // harmonic (src/potential.py:27) and diagonal Gaussian
     T cst;
     int D;
     int harmonic;
+    // mean / prec are stored zero-padded to a multiple of 64 entries (pbbi_api.hip::upload_padded):
+    // a padded dim (d >= D) has precision 0, mean 0, and its q, v, a are zero and stay zero, so its
+    // terms add exact zeros and no per-element guard is needed.
+    __device__ __forceinline__ T pr(int d) const { return prec[d]; }
+    __device__ __forceinline__ T mu(int d) const { return mean[d]; }
     __device__ __forceinline__ T U(const T (&q)[DMAX]) const {
         T acc = T(0);
         if (harmonic) {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d)
-                if (FULL || d < D) acc += prec[d] * (q[d] * q[d]);
+            for (int d = 0; d < DMAX; ++d) acc += pr(d) * (q[d] * q[d]);
         } else {
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d)
-                if (FULL || d < D) {
-                    const T x = q[d] - mean[d];
-                    acc += (prec[d] * x) * x;
-                }
+            for (int d = 0; d < DMAX; ++d) {
+                const T x = q[d] - mu(d);
+                acc += (pr(d) * x) * x;
+            }
         }
         return T(0.5) * acc + cst;
     }
     __device__ __forceinline__ void grad(const T (&q)[DMAX], T (&g)[DMAX]) const {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) g[d] = (FULL || d < D) ? prec[d] * (q[d] - mean[d]) : T(0);
+        for (int d = 0; d < DMAX; ++d) g[d] = pr(d) * (q[d] - mu(d));
     }
     // visit(d, g_d) for d = 0..DMAX-1 in order, one element at a time (no g[] array live)
     template <typename F>
     __device__ __forceinline__ void grad_each(const T (&q)[DMAX], F&& visit) const {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) visit(d, (FULL || d < D) ? prec[d] * (q[d] - mean[d]) : T(0));
+        for (int d = 0; d < DMAX; ++d) visit(d, pr(d) * (q[d] - mu(d)));
     }
 };
 
@@ -101,6 +104,22 @@ struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t_i = fma(-
         }
     }
 };
+
+// rows d >= D: loads read row 0 and the value is replaced by zero, stores go to a sink -- no branch
+// around a memory instruction (see SeparablePot)
+__device__ double g_lane_sink[BLOCK];
+
+template <typename T, bool FULL>
+__device__ __forceinline__ T load_row(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t row, int d, int D) {
+    const T x = buf_load<T>(r, voff, (FULL || d < D) ? (uint32_t)d * row : 0u);
+    return (FULL || d < D) ? x : T(0);
+}
+template <typename T, bool FULL>
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t r, __amdgpu_buffer_rsrc_t sink,
+                                          uint32_t voff, uint32_t row, int d, int D, T x) {
+    if constexpr (FULL) buf_store(r, voff, (uint32_t)d * row, x);
+    else buf_store((d < D) ? r : sink, voff, (d < D) ? (uint32_t)d * row : 0u, x);
+}
 
 // ---------------------------------------------------------------- integrators
 template <typename T, typename Pot, int DMAX, bool UNIT>
@@ -240,11 +259,12 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0);
     const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0);
     const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0);
+    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
     const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
 
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * rin) : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, rin, d, D);
     T u;
     if (prm.rng) {
         draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
@@ -252,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     } else {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * rin) : T(0);
+            p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
         u = prm.u_in[n];
     }
     const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
@@ -264,7 +284,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     if (reject) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (FULL || d < D) q[d] = buf_load<T>(bq, voff, (uint32_t)d * rin);  // :175
+            q[d] = load_row<T, FULL>(bq, voff, rin, d, D);  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -274,17 +294,17 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
             } else {
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d)
-                    if (FULL || d < D) p[d] = buf_load<T>(bp, voff, (uint32_t)d * rin);
+                    p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
             }
         }
     }
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        if (FULL || d < D) buf_store(bqo, voff, (uint32_t)d * rout, q[d]);
+        store_row<T, FULL>(bqo, bsink, voff, rout, d, D, q[d]);
     if (prm.p_out) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            if (FULL || d < D) buf_store(bpo, voff, (uint32_t)d * rout, p[d]);
+            store_row<T, FULL>(bpo, bsink, voff, rout, d, D, p[d]);
     }
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
@@ -313,19 +333,20 @@ __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot
     const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
     const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
     const __amdgpu_buffer_rsrc_t bv = buf_make(prm.v_out + n0);
+    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
-        q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
-        p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
+        q[d] = load_row<T, FULL>(bq, voff, row, d, D);
+        p[d] = load_row<T, FULL>(bp, voff, row, d, D);
     }
     integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        if (FULL || d < D) {
-            buf_store(bq, voff, (uint32_t)d * row, q[d]);
-            buf_store(bp, voff, (uint32_t)d * row, p[d]);
-            if (prm.v_out) buf_store(bv, voff, (uint32_t)d * row, v[d]);
+        {
+            store_row<T, FULL>(bq, bsink, voff, row, d, D, q[d]);
+            store_row<T, FULL>(bp, bsink, voff, row, d, D, p[d]);
+            if (prm.v_out) store_row<T, FULL>(bv, bsink, voff, row, d, D, v[d]);
         }
 }
 
@@ -350,9 +371,10 @@ __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
     const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
     const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
+    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
     T q[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (FULL || d < D) ? buf_load<T>(bq, voff, (uint32_t)d * row) : T(0);
+    for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, row, d, D);
     if (prm.mode == 0) {
         if (prm.U_out) prm.U_out[n] = pot.U(q);
         if (prm.grad_out) {
@@ -361,14 +383,14 @@ __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
             pot.grad(q, g);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                if (FULL || d < D) buf_store(bg, voff, (uint32_t)d * row, g[d]);
+                store_row<T, FULL>(bg, bsink, voff, row, d, D, g[d]);
         }
         return;
     }
     const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
     T p[DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) p[d] = (FULL || d < D) ? buf_load<T>(bp, voff, (uint32_t)d * row) : T(0);
+    for (int d = 0; d < DMAX; ++d) p[d] = load_row<T, FULL>(bp, voff, row, d, D);
     const T m = prm.mass ? prm.mass[n] : T(1);
     const T H = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
     if (prm.mode == 1) {

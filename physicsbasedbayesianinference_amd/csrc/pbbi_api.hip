@@ -74,11 +74,17 @@ int finish_or_destroy(int rc, pbbi_potential** out) {
     return rc;
 }
 
-int upload_mean(pbbi_potential* p, const double* mean) {
-    std::vector<double> mu((size_t)p->D, 0.0);
-    if (mean) std::memcpy(mu.data(), mean, sizeof(double) * p->D);
-    return upload(mu.data(), mu.size(), p->dtype, &p->d_mean);
+// D-element parameter vectors are stored zero-padded to a multiple of 64 entries: the register
+// kernels read rows d >= D of a padded chain with precision 0 / mean 0 instead of guarding them
+inline size_t padded64(int D) { return ((size_t)D + 63) / 64 * 64; }
+
+int upload_padded(const double* host, int D, int dtype, void** dev_out) {
+    std::vector<double> tmp(padded64(D), 0.0);
+    if (host) std::memcpy(tmp.data(), host, sizeof(double) * D);
+    return upload(tmp.data(), tmp.size(), dtype, dev_out);
 }
+
+int upload_mean(pbbi_potential* p, const double* mean) { return upload_padded(mean, p->D, p->dtype, &p->d_mean); }
 
 int check_common(const pbbi_potential* pot, int64_t N, int64_t ldn) {
     if (!pot) return pbbi_fail(PBBI_ERR_INVALID, "potential handle is NULL");
@@ -260,7 +266,7 @@ int pbbi_potential_create_harmonic(int D, const double* springConsts, int dtype,
     if (!springConsts) return pbbi_fail(PBBI_ERR_INVALID, "springConsts is NULL");
     if (int rc = new_handle(KIND_HARMONIC, D, dtype, device, out)) return rc;
     DeviceGuard guard(device);
-    int rc = upload(springConsts, (size_t)D, dtype, &(*out)->d_prec);
+    int rc = upload_padded(springConsts, D, dtype, &(*out)->d_prec);
     if (rc == PBBI_OK) rc = upload_mean(*out, nullptr);
     return finish_or_destroy(rc, out);
 }
@@ -271,7 +277,7 @@ int pbbi_potential_create_gauss_diag(int D, const double* mean, const double* pr
     if (int rc = new_handle(KIND_GAUSS_DIAG, D, dtype, device, out)) return rc;
     DeviceGuard guard(device);
     (*out)->cst = cst;
-    int rc = upload(prec, (size_t)D, dtype, &(*out)->d_prec);
+    int rc = upload_padded(prec, D, dtype, &(*out)->d_prec);
     if (rc == PBBI_OK) rc = upload_mean(*out, mean);
     return finish_or_destroy(rc, out);
 }
