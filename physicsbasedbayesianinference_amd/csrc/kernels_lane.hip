@@ -105,20 +105,24 @@ struct RosenbrockPot {  // U = (sum b t^2 + sum (a-q_i)^2) * (1/s),  t_i = fma(-
     }
 };
 
-// rows d >= D: loads read row 0 and the value is replaced by zero, stores go to a sink -- no branch
-// around a memory instruction (see SeparablePot)
-__device__ double g_lane_sink[BLOCK];
-
+// Rows d >= D of a zero-padded chain: the state arrays are addressed through descriptors bounded
+// to the array (pbbi_buf.h::buf_make_rows), so the hardware returns 0 for those loads and drops
+// those stores -- no branch around a memory instruction (a scalar branch per row makes hipcc put an
+// s_waitcnt between consecutive memory instructions).
 template <typename T, bool FULL>
-__device__ __forceinline__ T load_row(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t row, int d, int D) {
-    const T x = buf_load<T>(r, voff, (FULL || d < D) ? (uint32_t)d * row : 0u);
-    return (FULL || d < D) ? x : T(0);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const T* arr, int D, int64_t ld, int64_t N,
+                                                            int64_t n0) {
+    if constexpr (FULL) return buf_make(arr + n0);
+    else return buf_make_rows(arr + n0, D, ld, N, n0, (int)sizeof(T));
 }
 template <typename T, bool FULL>
-__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t r, __amdgpu_buffer_rsrc_t sink,
-                                          uint32_t voff, uint32_t row, int d, int D, T x) {
-    if constexpr (FULL) buf_store(r, voff, (uint32_t)d * row, x);
-    else buf_store((d < D) ? r : sink, voff, (d < D) ? (uint32_t)d * row : 0u, x);
+__device__ __forceinline__ T load_row(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t row, int d, int) {
+    return buf_load<T>(r, voff, (uint32_t)d * row);
+}
+template <typename T, bool FULL>
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t row, int d,
+                                          int, T x) {
+    buf_store(r, voff, (uint32_t)d * row, x);
 }
 
 // ---------------------------------------------------------------- integrators
@@ -255,11 +259,10 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
     const uint32_t rin = (uint32_t)prm.ldn_in * (uint32_t)sizeof(T);
     const uint32_t rout = (uint32_t)prm.ldn_out * (uint32_t)sizeof(T);
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0);
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0);
-    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
+    const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q_in, D, prm.ldn_in, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bp = rows_rsrc<T, FULL>(prm.p_in, D, prm.ldn_in, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bqo = rows_rsrc<T, FULL>(prm.q_out, D, prm.ldn_out, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(prm.p_out, D, prm.ldn_out, prm.N, n0);
     const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
 
     T q[DMAX], p[DMAX], v[DMAX];
@@ -300,11 +303,11 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     }
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
-        store_row<T, FULL>(bqo, bsink, voff, rout, d, D, q[d]);
+        store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
     if (prm.p_out) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            store_row<T, FULL>(bpo, bsink, voff, rout, d, D, p[d]);
+            store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
     }
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
@@ -330,10 +333,9 @@ __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot
     const T m = UNIT ? T(1) : prm.mass[n];
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
     const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
-    const __amdgpu_buffer_rsrc_t bv = buf_make(prm.v_out + n0);
-    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
+    const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q, D, prm.ldn, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bp = rows_rsrc<T, FULL>(prm.p, D, prm.ldn, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bv = rows_rsrc<T, FULL>(prm.v_out, D, prm.ldn, prm.N, n0);
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
@@ -344,9 +346,9 @@ __global__ void __launch_bounds__(BLOCK) k_lane_integrate(IntPrm<T> prm, Pot pot
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
         {
-            store_row<T, FULL>(bq, bsink, voff, row, d, D, q[d]);
-            store_row<T, FULL>(bp, bsink, voff, row, d, D, p[d]);
-            if (prm.v_out) store_row<T, FULL>(bv, bsink, voff, row, d, D, v[d]);
+            store_row<T, FULL>(bq, voff, row, d, D, q[d]);
+            store_row<T, FULL>(bp, voff, row, d, D, p[d]);
+            if (prm.v_out) store_row<T, FULL>(bv, voff, row, d, D, v[d]);
         }
 }
 
@@ -370,24 +372,23 @@ __global__ void __launch_bounds__(BLOCK) k_lane_eval(EvalPrm<T> prm, Pot pot) {
     const int D = prm.D;
     const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
     const uint32_t row = (uint32_t)prm.ldn * (uint32_t)sizeof(T);
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q + n0);
-    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_lane_sink);
+    const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q, D, prm.ldn, prm.N, n0);
     T q[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, row, d, D);
     if (prm.mode == 0) {
         if (prm.U_out) prm.U_out[n] = pot.U(q);
         if (prm.grad_out) {
-            const __amdgpu_buffer_rsrc_t bg = buf_make(prm.grad_out + n0);
+            const __amdgpu_buffer_rsrc_t bg = rows_rsrc<T, FULL>(prm.grad_out, D, prm.ldn, prm.N, n0);
             T g[DMAX];
             pot.grad(q, g);
 #pragma unroll
             for (int d = 0; d < DMAX; ++d)
-                store_row<T, FULL>(bg, bsink, voff, row, d, D, g[d]);
+                store_row<T, FULL>(bg, voff, row, d, D, g[d]);
         }
         return;
     }
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p + n0);
+    const __amdgpu_buffer_rsrc_t bp = rows_rsrc<T, FULL>(prm.p, D, prm.ldn, prm.N, n0);
     T p[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) p[d] = load_row<T, FULL>(bp, voff, row, d, D);

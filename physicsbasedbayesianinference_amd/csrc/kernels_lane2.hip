@@ -192,15 +192,17 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
     const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
     const uint32_t vin = 8u * (uint32_t)cc + (uint32_t)(16 * half) * rin;
     const uint32_t vout = 8u * (uint32_t)cc + (uint32_t)(16 * half) * rout;
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0);
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0);
+    // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): half 1's rows past D read 0 and
+    // drop their stores in hardware, no per-lane predication around the memory instructions
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0, D, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return pot.exists(j); };
 
     double q[DL], v[DL], a[DL];  // v holds p, then the velocity, then p again
 #pragma unroll
-    for (int j = 0; j < DL; ++j) q[j] = exists(j) ? buf_load<double>(bq, vin, (uint32_t)j * rin) : 0.0;
+    for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
     auto draw = [&]() {
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
     };
     auto load_p = [&]() {
 #pragma unroll
-        for (int j = 0; j < DL; ++j) v[j] = exists(j) ? buf_load<double>(bp, vin, (uint32_t)j * rin) : 0.0;
+        for (int j = 0; j < DL; ++j) v[j] = buf_load<double>(bp, vin, (uint32_t)j * rin);
     };
     if (prm.rng) draw(); else load_p();
 
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
     if (reject) {
 #pragma unroll
         for (int j = 0; j < DL; ++j)
-            if (exists(j)) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
+            q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -291,11 +293,11 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
     if (valid) {
 #pragma unroll
         for (int j = 0; j < DL; ++j)
-            if (exists(j)) buf_store(bqo, vout, (uint32_t)j * rout, q[j]);
+            buf_store(bqo, vout, (uint32_t)j * rout, q[j]);
         if (prm.p_out) {
 #pragma unroll
             for (int j = 0; j < DL; ++j)
-                if (exists(j)) buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
+                buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
         }
         if (half == 0) {
             if (prm.ratio_out) prm.ratio_out[n0 + cb] = ratio;

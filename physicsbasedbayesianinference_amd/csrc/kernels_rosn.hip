@@ -40,8 +40,6 @@ struct RosPrm {
     uint64_t seed, iter, chain0;
 };
 
-__device__ double g_sink_ros[64];  // stores of dims past D (see kernels_sepn.hip)
-
 // GMAX: upper bound on the waves per workgroup of this instantiation (4: D <= 64, 256-thread blocks
 // may use 168 VGPRs at three waves per SIMD; 16: D <= 256, 128 VGPRs)
 template <bool UNIT, bool FULL, int GMAX>
@@ -62,23 +60,18 @@ __global__ void __launch_bounds__(64 * GMAX, (GMAX <= 4 ? 3 : 1)) k_rosn_hmc(Ros
     const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
     const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
     const uint32_t vo = 8u * (uint32_t)cc;
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in);
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out);
-    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_sink_ros);
+    // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): rows past D read 0 / drop stores
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return FULL || d0 + j < D; };       // wave-uniform
     auto has_next = [&](int j) {                                    // dim d0+j has a right neighbour
         if constexpr (FULL) return j + 1 < DL ? true : part + 1 < G;
         return d0 + j + 1 < D;
     };
-    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) {
-        return buf_load<double>(r, vo, exists(j) ? (uint32_t)j * rin : 0u);
-    };
-    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) {
-        if constexpr (FULL) buf_store(r, vo, (uint32_t)j * rout, x);
-        else buf_store(exists(j) ? r : bsink, vo, exists(j) ? (uint32_t)j * rout : 0u, x);
-    };
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) { return buf_load<double>(r, vo, (uint32_t)j * rin); };
+    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) { buf_store(r, vo, (uint32_t)j * rout, x); };
 
     double q[DL], v[DL];
 #pragma unroll

@@ -45,11 +45,6 @@ struct SepPrm {
 
 // FULL: D is a multiple of 16, every dim of every part exists: no guards (as scalar branches they
 // put an s_waitcnt between consecutive loads / stores)
-// Stores of dims past D (last part when D is not a multiple of 16) go here instead of being
-// branched around: a scalar branch per row puts an s_waitcnt between consecutive memory
-// instructions (measured at D = 100: 0.41 of the HBM roofline with branches, vs 0.8-0.9 at D = 128).
-__device__ double g_sink[64];
-
 template <bool UNIT, bool FULL>
 __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     __shared__ double dH[MAXG][64];
@@ -66,28 +61,21 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
     const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
     const uint32_t vo = 8u * (uint32_t)cc;
-    const __amdgpu_buffer_rsrc_t bq = buf_make(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in);
-    const __amdgpu_buffer_rsrc_t bp = buf_make(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out);
+    // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): rows past D read 0 / drop stores
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return FULL || d0 + j < D; };  // wave-uniform
-    const __amdgpu_buffer_rsrc_t bsink = buf_make(g_sink);
-    // row j of an input array, clamped to an existing row (the value is discarded by a select)
-    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) {
-        return buf_load<double>(r, vo, exists(j) ? (uint32_t)j * rin : 0u);
-    };
-    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) {
-        if constexpr (FULL) buf_store(r, vo, (uint32_t)j * rout, x);
-        else buf_store(exists(j) ? r : bsink, vo, exists(j) ? (uint32_t)j * rout : 0u, x);
-    };
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) { return buf_load<double>(r, vo, (uint32_t)j * rin); };
+    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) { buf_store(r, vo, (uint32_t)j * rout, x); };
 
     // this part's constants (SGPRs); a dim past D gets prec = 0 and stays at x = v = 0
     double mu[DL], pr[DL];
 #pragma unroll
     for (int j = 0; j < DL; ++j) {
-        const int d = exists(j) ? d0 + j : D - 1;
-        mu[j] = prm.mean[d];
-        pr[j] = exists(j) ? prm.prec[d] : 0.0;
+        mu[j] = prm.mean[d0 + j];  // parameter vectors are zero-padded to a multiple of 64
+        pr[j] = prm.prec[d0 + j];
     }
     const double h = prm.h, nhm = UNIT ? -h : -(h / m), nhh = 0.5 * nhm;
     double q[DL], v[DL];  // q holds x = q - mu between the load and the store

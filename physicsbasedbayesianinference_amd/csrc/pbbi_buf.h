@@ -20,6 +20,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_make(const void* base) {
                                              /*num_records*/ 0xFFFFFFF0u, /*flags*/ 0x00020000);
 }
 
+// Bounded descriptor: num_records = the bytes that remain from `base` to the end of a (D, N) array.
+// gfx950 range-checks voffset + soffset against it (tools/ubench/buffer_oob.hip): a load past the
+// end returns 0 and a store past the end is dropped, so the rows d >= D of a zero-padded chain need
+// neither a branch, a clamp nor a sink.  `base` = array + n0 (first chain of the block).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_make_rows(const void* base, int D, int64_t ld,
+                                                                int64_t N, int64_t n0, int elem) {
+    const int64_t bytes = ((int64_t)(D - 1) * ld + N - n0) * elem;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0,
+                                             (unsigned)(bytes > 0 ? bytes : 0), /*flags*/ 0x00020000);
+}
+
 template <typename T>
 __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff_bytes,
                                       uint32_t soff_bytes);
