@@ -36,11 +36,19 @@ namespace {
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, NTHR = 256;
+constexpr int BM = 128, BN = 128;
 
+// Block tile 128 x 128 for both types.  fp32: 4 waves (2 x 2), 64 x 64 per wave (64 accumulator
+// registers).  fp64: the same wave tile needs 128 accumulator registers and ran at one wave per SIMD
+// (328 registers: 0.27-0.47 of the fp64 MFMA peak at D = 256...1024); with 8 waves (2 x 4), 64 x 32
+// per wave, it fits 128 registers: two workgroups per CU, four waves per SIMD.
 template <typename T> struct Cfg;
-template <> struct Cfg<float> { static constexpr int BK = 32; };
-template <> struct Cfg<double> { static constexpr int BK = 16; };
+template <> struct Cfg<float> {
+    static constexpr int BK = 32, NTHR = 256, WAVES_N = 2, WTN = 64, MIN_WAVES = 2;
+};
+template <> struct Cfg<double> {
+    static constexpr int BK = 16, NTHR = 512, WAVES_N = 4, WTN = 32, MIN_WAVES = 4;
+};
 
 enum { EPI_EVAL = 0, EPI_KDK = 1 };
 
@@ -102,28 +110,27 @@ struct MmaF32 {
     }
 };
 
-struct MmaF64 {
-    v4f64 acc[4][4];
+struct MmaF64 {  // 64 x 32 per wave: 4 x 2 tiles of 16 x 16
+    v4f64 acc[4][2];
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+            for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
     }
     __device__ __forceinline__ void tile(const double* As, const double* Bs, int wm, int wn, int lane) {
         const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
         for (int kk = 0; kk < Cfg<double>::BK; kk += 4) {
-            double a[4], b[4];
+            double a[4], b[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = As[(kk + kq) * BM + wm + 16 * t + r];  // A[i = r][k = kq]
-                b[t] = Bs[(kk + kq) * BN + wn + 16 * t + r];  // B[k = kq][n = r]
-            }
+            for (int t = 0; t < 4; ++t) a[t] = As[(kk + kq) * BM + wm + 16 * t + r];  // A[i = r][k = kq]
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = Bs[(kk + kq) * BN + wn + 16 * t + r];  // B[k = kq][n = r]
 #pragma unroll
             for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
+                for (int tb = 0; tb < 2; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
     }
@@ -133,7 +140,7 @@ struct MmaF64 {
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
+            for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     f(wm + 16 * ta + (lane >> 4) + 4 * r, wn + 16 * tb + (lane & 15), tb, acc[ta][tb][r]);
@@ -146,15 +153,15 @@ template <> struct MmaOf<double> { using type = MmaF64; };
 
 // ---- the GEMM with fused epilogue ----------------------------------------------------------------
 template <typename T, int EPI, bool ZMEAN>
-__global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
-    constexpr int BK = Cfg<T>::BK;
+__global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(GemmPrm<T> prm) {
+    constexpr int BK = Cfg<T>::BK, NTHR = Cfg<T>::NTHR, WAVES_N = Cfg<T>::WAVES_N;
     extern __shared__ __attribute__((aligned(16))) char smem_big[];
     T (*As)[BK * BM] = reinterpret_cast<T (*)[BK * BM]>(smem_big);                      // [2]
     T (*Bs)[BK * BN] = reinterpret_cast<T (*)[BK * BN]>(smem_big + 2 * BK * BM * sizeof(T));  // [2]
     T (*red)[BN] = reinterpret_cast<T (*)[BN]>(smem_big + 4 * BK * BM * sizeof(T));    // [2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * Cfg<T>::WTN;
     const int n_tiles_m = prm.DPAD / BM;
     const int bm = blockIdx.x % n_tiles_m, bn = blockIdx.x / n_tiles_m;  // a P^T panel's tiles are
     const int i0 = bm * BM;                                              // consecutive: spread over XCDs
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
     // ---- epilogue
     // both C/D maps give a lane one fixed column per column-tile tb and several rows:
     // accumulate x.g per tb, then combine the lanes that share the column
-    constexpr int NTB = sizeof(T) == 4 ? 2 : 4;
+    constexpr int NTB = 2;  // column tiles per wave: 2 x 32 (fp32) or 2 x 16 (fp64)
     T xg[NTB];
 #pragma unroll
     for (int b = 0; b < NTB; ++b) xg[b] = T(0);
@@ -275,7 +282,7 @@ __global__ void __launch_bounds__(NTHR) k_big_gemm(GemmPrm<T> prm) {
             }
             const int nl = wn + b * (sizeof(T) == 4 ? 32 : 16) + (lane & (sizeof(T) == 4 ? 31 : 15));
             const bool writer = sizeof(T) == 4 ? (lane < 32) : (lane < 16);
-            if (writer) red[wave >> 1][nl] = s;
+            if (writer) red[wave / WAVES_N][nl] = s;
         }
         __syncthreads();
         if (tid < BN && n0 + tid < prm.N)
@@ -441,7 +448,7 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
     auto go = [&](auto kernel) -> int {
         PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NTHR), lds, st, prm);
+        hipLaunchKernelGGL(kernel, dim3(tiles), dim3(Cfg<T>::NTHR), lds, st, prm);
         return PBBI_OK;
     };
     int rc;
