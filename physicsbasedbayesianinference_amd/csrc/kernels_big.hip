@@ -421,20 +421,6 @@ __global__ void k_big_inv(const T* mass, T* minv, int64_t N) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-struct Workspace {  // stream-ordered scratch for one call
-    hipStream_t st;
-    std::vector<void*> ptrs;
-    explicit Workspace(hipStream_t s) : st(s) {}
-    void* get(size_t bytes) {
-        void* p = nullptr;
-        if (hipMallocAsync(&p, bytes ? bytes : 16, st) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return p;
-    }
-    ~Workspace() {
-        for (void* p : ptrs) (void)hipFreeAsync(p, st);
-    }
-};
 
 constexpr int SQ_ROWS = 256;  // rows per block of the p^2 column reduction
 
@@ -469,7 +455,7 @@ int run_hmc(const IterArgs& a) {
     const int D = pot->D, L = a.L;
     const int64_t N = a.N;
     hipStream_t st = a.stream;
-    Workspace ws(st);
+    Scratch ws(a);
     const size_t slab = (size_t)D * N * sizeof(T);
     const int n_xg = pot->DPAD_big / BM, n_sq = (D + SQ_ROWS - 1) / SQ_ROWS;
     T* vh = (T*)ws.get(slab);
@@ -547,7 +533,7 @@ int run_integrate(const IntegrateArgs& a) {
     const int D = pot->D, L = a.L;
     const int64_t N = a.N;
     hipStream_t st = a.stream;
-    Workspace ws(st);
+    Scratch ws(st);
     const size_t slab = (size_t)D * N * sizeof(T);
     T* vh = (T*)ws.get(slab);
     T* qa = (T*)ws.get(slab);
@@ -590,7 +576,7 @@ int run_eval(const EvalArgs& a, int mode) {
     const int D = pot->D;
     const int64_t N = a.N;
     hipStream_t st = a.stream;
-    Workspace ws(st);
+    Scratch ws(st);
     const int n_xg = pot->DPAD_big / BM, n_sq = (D + SQ_ROWS - 1) / SQ_ROWS;
     T* xg = (T*)ws.get((size_t)n_xg * N * sizeof(T));
     T* pp = mode ? (T*)ws.get((size_t)n_sq * N * sizeof(T)) : nullptr;

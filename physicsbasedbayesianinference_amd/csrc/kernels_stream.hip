@@ -455,27 +455,13 @@ void with_method_unit(int method, bool unit, F&& f) {
     }
 }
 
-struct Workspace {  // stream-ordered scratch for one call
-    hipStream_t st;
-    std::vector<void*> ptrs;
-    explicit Workspace(hipStream_t s) : st(s) {}
-    void* get(size_t bytes) {
-        void* p = nullptr;
-        if (hipMallocAsync(&p, bytes ? bytes : 16, st) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return p;
-    }
-    ~Workspace() {
-        for (void* p : ptrs) (void)hipFreeAsync(p, st);
-    }
-};
 
 inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + SB - 1) / SB)); }
 
 template <typename T>
 int run_hmc(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
-    Workspace ws(a.stream);
+    Scratch ws(a);
     const size_t slab = (size_t)pot->D * a.N * sizeof(T);
     T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab);
     if (!Wq || !Wv || !Wa) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the chain workspace");
@@ -498,7 +484,7 @@ int run_hmc(const IterArgs& a) {
 template <typename T>
 int run_integrate(const IntegrateArgs& a) {
     const pbbi_potential* pot = a.pot;
-    Workspace ws(a.stream);
+    Scratch ws(a.stream);
     const size_t slab = (size_t)pot->D * a.N * sizeof(T);
     T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab);
     if (!Wq || !Wv || !Wa) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the chain workspace");

@@ -465,6 +465,10 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
     DeviceGuard guard(pot->device);
     const size_t es = elem_size(pot->dtype);
     const size_t slab = (size_t)pot->D * (size_t)N;  // elements per (D, N) sample slab
+    // paths that need device scratch (GEMM, workspace-streaming, user plugins) report what they
+    // took in iteration 0; iterations 1.. carve the same from ONE arena instead of allocating again
+    size_t need = 0;
+    void* arena = nullptr;
     for (int i = 0; i < S; ++i) {
         IterArgs a{};
         a.pot = pot; a.method = method; a.mass = mass;
@@ -479,8 +483,16 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         a.N = N; a.h = h; a.L = L; a.flags = flags;
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = (hipStream_t)stream;
-        if (int rc = route_hmc(a)) return rc;
+        a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
+        if (int rc = route_hmc(a)) {
+            if (arena) (void)hipFreeAsync(arena, (hipStream_t)stream);
+            return rc;
+        }
+        if (i == 0 && need > 0 && S > 1 &&
+            hipMallocAsync(&arena, need, (hipStream_t)stream) != hipSuccess)
+            arena = nullptr;  // keep allocating per iteration
     }
+    if (arena) PBBI_HIP(hipFreeAsync(arena, (hipStream_t)stream));
     // leave the chain state in q_state (strided D2D copy of the last slab)
     PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * es,
                               (const char*)samples_out + (size_t)(S - 1) * slab * es, (size_t)N * es,

@@ -529,20 +529,6 @@ __global__ void __launch_bounds__(RB) k_custom_reg_integrate(IntPrm prm) {
     }
 }
 
-struct Workspace {  // stream-ordered scratch for one call
-    hipStream_t st;
-    std::vector<void*> ptrs;
-    explicit Workspace(hipStream_t s) : st(s) {}
-    T* get(size_t elems) {
-        void* p = nullptr;
-        if (hipMallocAsync(&p, (elems ? elems : 2) * sizeof(T), st) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return (T*)p;
-    }
-    ~Workspace() {
-        for (void* p : ptrs) (void)hipFreeAsync(p, st);
-    }
-};
 
 inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + SB - 1) / SB)); }
 
@@ -606,9 +592,9 @@ int pbbi_plugin_hmc_iter(const IterArgs* a) {
     using namespace pbbi_custom;
     const pbbi_potential* pot = a->pot;
     if (REG_OK && pot->D == RD) return reg_hmc<REG_OK>(a);  // the chain fits the lane's registers
-    Workspace ws(a->stream);
-    const size_t slab = (size_t)pot->D * a->N;
-    T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);
+    Scratch ws(*a);
+    const size_t slab = (size_t)pot->D * a->N * sizeof(T);
+    T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab), *Wg = (T*)ws.get(slab);
     if (!Wq || !Wv || !Wa || !Wg) return -1;
     HmcPrm prm{(const T*)a->q_in, (const T*)a->p_in, (const T*)a->u_in, (const T*)a->mass,
                (T*)a->q_out, (T*)a->p_out, (T*)a->ratio_out, a->reject_out,
@@ -625,9 +611,9 @@ int pbbi_plugin_integrate(const IntegrateArgs* a) {
     using namespace pbbi_custom;
     const pbbi_potential* pot = a->pot;
     if (REG_OK && pot->D == RD) return reg_integrate<REG_OK>(a);
-    Workspace ws(a->stream);
-    const size_t slab = (size_t)pot->D * a->N;
-    T *Wq = ws.get(slab), *Wv = ws.get(slab), *Wa = ws.get(slab), *Wg = ws.get(slab);
+    Scratch ws(a->stream);
+    const size_t slab = (size_t)pot->D * a->N * sizeof(T);
+    T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab), *Wg = (T*)ws.get(slab);
     if (!Wq || !Wv || !Wa || !Wg) return -1;
     IntPrm prm{(T*)a->q, (T*)a->p, (const T*)a->mass, (T*)a->v_out, a->N, a->ldn, (T)a->h, a->L,
                pot->D, (const T*)pot->d_params, Wq, Wv, Wa, Wg};

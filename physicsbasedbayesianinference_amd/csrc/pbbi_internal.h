@@ -10,7 +10,7 @@
 enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3, KIND_CUSTOM = 4 };
 
 // layout version of the structs a user-potential plugin (pbbi_custom.h) shares with libpbbi.so
-#define PBBI_PLUGIN_ABI 1
+#define PBBI_PLUGIN_ABI 2
 
 struct IterArgs;
 struct IntegrateArgs;
@@ -86,6 +86,12 @@ struct IterArgs {
     uint64_t seed, iter, chain0;
     double kT;
     hipStream_t stream;
+    // scratch arena lent by pbbi_hmc_run (all its iterations run on one stream, one after the other):
+    // paths that need device scratch carve it from here instead of allocating every iteration, and
+    // report the bytes they asked for through scratch_used (how the first iteration sizes the arena)
+    void* scratch;
+    size_t scratch_bytes;
+    size_t* scratch_used;
 };
 
 struct IntegrateArgs {
@@ -112,6 +118,36 @@ struct EvalArgs {
     void* w_out;     // energy only: exp(-H)
     int ratio_finish;  // energy only: U_out[n] = exp(U_out[n] - H)   (src/HMC.py:115)
     hipStream_t stream;
+};
+
+// Device scratch for one call: from the arena an IterArgs lends, else stream-ordered allocations.
+#include <vector>
+struct Scratch {
+    hipStream_t st;
+    char* base = nullptr;
+    size_t cap = 0, off = 0, total = 0;
+    size_t* used = nullptr;
+    std::vector<void*> owned;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    explicit Scratch(const IterArgs& a)
+        : st(a.stream), base((char*)a.scratch), cap(a.scratch ? a.scratch_bytes : 0), used(a.scratch_used) {}
+    void* get(size_t bytes) {
+        bytes = ((bytes ? bytes : 16) + 255) / 256 * 256;
+        total += bytes;
+        if (base && off + bytes <= cap) {
+            void* p = base + off;
+            off += bytes;
+            return p;
+        }
+        void* p = nullptr;
+        if (hipMallocAsync(&p, bytes, st) != hipSuccess) return nullptr;
+        owned.push_back(p);
+        return p;
+    }
+    ~Scratch() {
+        for (void* p : owned) (void)hipFreeAsync(p, st);
+        if (used) *used = total;
+    }
 };
 
 // chain-per-lane kernels (harmonic / diagonal Gaussian / Rosenbrock), kernels_lane.hip

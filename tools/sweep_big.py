@@ -19,4 +19,9 @@ def run(D, N, dtype, K=5, W=2, L=10, h=0.1):
     t0 = time.perf_counter(); go(K, W); torch.cuda.synchronize(); t = (time.perf_counter() - t0) / K
     fl = (L + 1) * 2.0 * D * D * N
     print(json.dumps({"D": D, "N": N, "dtype": dtype, "ms_per_iter": t * 1e3, "TFLOPs": fl / t / 1e12, "rate": L * N / t}), flush=True)
-run(256, 65536, "float64"); run(512, 32768, "float64"); run(1024, 16384, "float64"); run(1024, 16384, "float32"); run(256, 65536, "float32")
+if __name__ == "__main__":
+    cfgs = sys.argv[1:] or ["256:65536:float64", "512:32768:float64", "1024:16384:float64",
+                            "1024:16384:float32", "256:65536:float32"]
+    for c in cfgs:
+        d, n, t = c.split(":")
+        run(int(d), int(n), t)
