@@ -245,7 +245,126 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
         __syncthreads();
     }
 
-    // ---- epilogue
+    // ---- epilogue, fp32 interior tiles: staged through LDS
+    // In the MFMA C/D layout a lane owns 64 scattered elements: 256 four-byte global accesses per
+    // lane (q, vh in; vh, q_next out).  The tile goes through LDS instead (the operand buffers are
+    // free after the last step) and comes back row-major: thread (rg = tid/32, cg = tid%32) handles
+    // columns 4cg..4cg+3 of rows rg, rg+8, ..: 16-byte accesses, 64 per thread, 512 B per row
+    // segment.  Matters when K = D is small and the epilogue is a large share of the tile's time.
+    // Edge tiles, unaligned strides and fp64 keep the per-element path below.
+    if constexpr (sizeof(T) == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        constexpr int CS = BN + 4;  // padded row stride of the staged tile
+        constexpr int RGS = NTHR / 32;  // row groups
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        bool staged = (i0 + BM <= prm.D) && (n0 + BN <= prm.N) && q_vec_ok;
+        if constexpr (EPI == EPI_EVAL)
+            staged = staged && (!prm.grad_out || (prm.ldg % 4 == 0 && al16(prm.grad_out)));
+        else
+            staged = staged && prm.ldw % 4 == 0 && al16(prm.vh) && (!prm.q_next || al16(prm.q_next)) &&
+                     (!prm.minv || al16(prm.minv));
+        if (staged) {  // block-uniform
+            float* Cst = reinterpret_cast<float*>(smem_big);  // [BM][CS]
+            float* red2 = Cst + BM * CS;                      // [RGS][BN]
+            mma.each(wm, wn, lane, [&](int il, int nl, int, T g) { Cst[il * CS + nl] = g; });
+            __syncthreads();
+            const int cg = tid & 31, rg = tid >> 5;
+            const int64_t n = n0 + 4 * cg;
+            f4 xg4 = {0.f, 0.f, 0.f, 0.f};
+            f4 mi4 = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (EPI == EPI_KDK)
+                if (prm.minv) mi4 = *reinterpret_cast<const f4*>(prm.minv + n);
+#pragma unroll 4
+            for (int pss = 0; pss < BM / RGS; ++pss) {
+                const int il = pss * RGS + rg;
+                const int i = i0 + il;
+                const f4 g = *reinterpret_cast<const f4*>(&Cst[il * CS + 4 * cg]);
+                const f4 qv = *reinterpret_cast<const f4*>(prm.q + (int64_t)i * prm.ldq + n);
+                const f4 x = ZMEAN ? qv : qv - prm.mu[i];
+                xg4 += x * g;
+                if constexpr (EPI == EPI_EVAL) {
+                    if (prm.grad_out) *reinterpret_cast<f4*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;
+                } else {
+                    const int64_t o = (int64_t)i * prm.ldw + n;
+                    const f4 v = *reinterpret_cast<const f4*>(prm.vh + o) + (-(g * mi4)) * prm.hk;  // kick
+                    *reinterpret_cast<f4*>(prm.vh + o) = v;
+                    if (prm.q_next) *reinterpret_cast<f4*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                }
+            }
+            if (prm.xg_part) {
+                *reinterpret_cast<f4*>(&red2[rg * BN + 4 * cg]) = xg4;
+                __syncthreads();
+                if (tid < BN) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RGS; ++r) s += red2[r * BN + tid];
+                    prm.xg_part[(size_t)bm * prm.N + n0 + tid] = s;
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- epilogue, fp64 interior tiles: the same staging in two halves of 64 rows (64 KiB each, the
+    // size of the operand buffers), 16-byte (two-element) accesses
+    if constexpr (sizeof(T) == 8) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        constexpr int RGS = NTHR / 64;  // row groups of the read phase (64 column pairs per row)
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        bool staged = (i0 + BM <= prm.D) && (n0 + BN <= prm.N) && q_vec_ok;
+        if constexpr (EPI == EPI_EVAL)
+            staged = staged && (!prm.grad_out || (prm.ldg % 2 == 0 && al16(prm.grad_out)));
+        else
+            staged = staged && prm.ldw % 2 == 0 && al16(prm.vh) && (!prm.q_next || al16(prm.q_next)) &&
+                     (!prm.minv || al16(prm.minv));
+        if (staged) {  // block-uniform
+            double* Cst = reinterpret_cast<double*>(smem_big);  // [64][BN]
+            const int cg = tid & 63, rg = tid >> 6;
+            const int64_t n = n0 + 2 * cg;
+            d2 xg2 = {0.0, 0.0};
+            d2 mi2 = {1.0, 1.0};
+            if constexpr (EPI == EPI_KDK)
+                if (prm.minv) mi2 = *reinterpret_cast<const d2*>(prm.minv + n);
+#pragma unroll 1
+            for (int hrow = 0; hrow < BM; hrow += 64) {
+                if (hrow) __syncthreads();  // the previous half has been read
+                if (wm == hrow)
+                    mma.each(wm, wn, lane, [&](int il, int nl, int, T g) { Cst[(il - hrow) * BN + nl] = g; });
+                __syncthreads();
+#pragma unroll 4
+                for (int pss = 0; pss < 64 / RGS; ++pss) {
+                    const int il = pss * RGS + rg;
+                    const int i = i0 + hrow + il;
+                    const d2 g = *reinterpret_cast<const d2*>(&Cst[il * BN + 2 * cg]);
+                    const d2 qv = *reinterpret_cast<const d2*>(prm.q + (int64_t)i * prm.ldq + n);
+                    const d2 x = ZMEAN ? qv : qv - prm.mu[i];
+                    xg2 += x * g;
+                    if constexpr (EPI == EPI_EVAL) {
+                        if (prm.grad_out) *reinterpret_cast<d2*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;
+                    } else {
+                        const int64_t o = (int64_t)i * prm.ldw + n;
+                        const d2 v = *reinterpret_cast<const d2*>(prm.vh + o) + (-(g * mi2)) * prm.hk;  // kick
+                        *reinterpret_cast<d2*>(prm.vh + o) = v;
+                        if (prm.q_next) *reinterpret_cast<d2*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                    }
+                }
+            }
+            if (prm.xg_part) {
+                __syncthreads();  // the staged tile is dead: its space takes the partial sums [RGS][BN]
+                *reinterpret_cast<d2*>(&Cst[rg * BN + 2 * cg]) = xg2;
+                __syncthreads();
+                if (tid < BN) {
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RGS; ++r) s2 += Cst[r * BN + tid];
+                    prm.xg_part[(size_t)bm * prm.N + n0 + tid] = s2;
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- epilogue, general path
     // both C/D maps give a lane one fixed column per column-tile tb and several rows:
     // accumulate x.g per tb, then combine the lanes that share the column
     constexpr int NTB = 2;  // column tiles per wave: 2 x 32 (fp32) or 2 x 16 (fp64)
@@ -430,7 +549,11 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
     GemmPrm<T> prm{(const T*)pot->d_big_PT, (const T*)pot->d_big_mu, q, q_next, vh, minv, grad_out,
                    xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h};
     const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
-    const size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
+    size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
+    if (sizeof(T) == 4) {  // the staged fp32 epilogue: [BM][BN+4] tile + [NTHR/32][BN] partial sums
+        const size_t staged = (size_t)BM * (BN + 4) * sizeof(T) + (size_t)(Cfg<T>::NTHR / 32) * BN * sizeof(T);
+        if (staged > lds) lds = staged;
+    }
     auto go = [&](auto kernel) -> int {
         PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
