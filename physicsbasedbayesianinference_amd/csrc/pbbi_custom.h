@@ -370,11 +370,14 @@ __global__ void __launch_bounds__(SB) k_custom_eval(EvalPrm prm) {
 // constants -- the same shape as kernels_lane.hip (one chain per lane, state on chip for all L
 // steps, HBM touched once on the way in and once on the way out), at the same operation order.
 #if defined(PBBI_D)
+// reference operation order: q, v, a, g live (4*D values); kick-drift-kick/FMA form (PBBI_KDK_FMA):
+// q, v, g (3*D values) -- twice the dimension fits
 constexpr int REG_DMAX = sizeof(T) == 8 ? 16 : 32;
 constexpr bool REG_OK = (PBBI_D) <= REG_DMAX;
-constexpr int RD = REG_OK ? (PBBI_D) : 1;
+constexpr bool REG_OK_KDK = (PBBI_D) <= 2 * REG_DMAX;
+constexpr int RD = REG_OK_KDK ? (PBBI_D) : 1;
 #else
-constexpr bool REG_OK = false;
+constexpr bool REG_OK = false, REG_OK_KDK = false;
 constexpr int RD = 1;
 #endif
 constexpr int RB = 256;  // chains per workgroup
@@ -385,9 +388,28 @@ struct Vec {
     __device__ __forceinline__ const T& operator[](int j) const { return x[j]; }
 };
 
-template <int METHOD, bool UNIT>
+template <int METHOD, bool UNIT, bool KDK = false>
 __device__ __forceinline__ void reg_trajectory(Vec& q, Vec& v, const T* prm, T m, T h, int L) {
     const T h2 = h * h, half = T(0.5), hh = half * h, hh2 = half * h2;
+    if constexpr (KDK) {
+        // PBBI_KDK_FMA: vh = v + a0 h/2;  L x { q += vh h; vh += a(q) h }, the last kick a half kick
+        const T hm = UNIT ? h : h / m, hhm = half * hm;
+        Vec g;
+        if (L > 0) {
+            user::gradient(q, g, RD, prm);
+#pragma unroll
+            for (int j = 0; j < RD; ++j) v[j] = fma(-g[j], hhm, v[j]);
+            for (int s = 0; s < L; ++s) {
+#pragma unroll
+                for (int j = 0; j < RD; ++j) q[j] = fma(v[j], h, q[j]);
+                user::gradient(q, g, RD, prm);
+                const T kk = (s + 1 < L) ? hm : hhm;
+#pragma unroll
+                for (int j = 0; j < RD; ++j) v[j] = fma(-g[j], kk, v[j]);
+            }
+        }
+        return;
+    }
     Vec a, g;
     if constexpr (METHOD == PBBI_LEAPFROG) {
         user::gradient(q, g, RD, prm);
@@ -427,7 +449,7 @@ __device__ __forceinline__ void reg_trajectory(Vec& q, Vec& v, const T* prm, T m
     }
 }
 
-template <int METHOD, bool UNIT>
+template <int METHOD, bool UNIT, bool KDK = false>
 __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
     const int64_t n = (int64_t)blockIdx.x * RB + threadIdx.x;
     if (n >= prm.N) return;
@@ -472,7 +494,7 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) v[j] = v[j] / m;
     }
-    reg_trajectory<METHOD, UNIT>(q, v, prm.prm, m, prm.h, prm.L);
+    reg_trajectory<METHOD, UNIT, KDK>(q, v, prm.prm, m, prm.h, prm.L);
     if constexpr (!UNIT) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) v[j] = v[j] * m;  // p = v*m
@@ -545,7 +567,7 @@ void with_method_unit(int method, bool unit, F&& f) {
 
 // launchers of the register-resident kernels; templates so that a plugin whose D does not fit
 // never instantiates them (nor the user's functions on a one-element array)
-template <bool R>
+template <bool R, bool KDK = false>
 int reg_hmc(const IterArgs* a) {
     if constexpr (R) {
         const pbbi_potential* pot = a->pot;
@@ -554,10 +576,19 @@ int reg_hmc(const IterArgs* a) {
                    a->N, a->ldn_in, a->ldn_out, (T)a->h, a->L, pot->D, a->flags, a->rng,
                    a->seed, a->iter, a->chain0, a->kT, (const T*)pot->d_params, nullptr, nullptr,
                    nullptr, nullptr};
-        with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
-            hipLaunchKernelGGL((k_custom_reg_hmc<decltype(meth)::value, decltype(unit)::value>),
-                               dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
-        });
+        if constexpr (KDK) {  // Leapfrog only
+            if (a->mass == nullptr)
+                hipLaunchKernelGGL((k_custom_reg_hmc<PBBI_LEAPFROG, true, true>),
+                                   dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
+            else
+                hipLaunchKernelGGL((k_custom_reg_hmc<PBBI_LEAPFROG, false, true>),
+                                   dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
+        } else {
+            with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+                hipLaunchKernelGGL((k_custom_reg_hmc<decltype(meth)::value, decltype(unit)::value>),
+                                   dim3((unsigned)((a->N + RB - 1) / RB)), dim3(RB), 0, a->stream, prm);
+            });
+        }
         return (int)hipGetLastError();
     } else {
         return -1;
@@ -591,7 +622,10 @@ int pbbi_plugin_dtype(void) { return sizeof(T) == 8 ? PBBI_F64 : PBBI_F32; }
 int pbbi_plugin_hmc_iter(const IterArgs* a) {
     using namespace pbbi_custom;
     const pbbi_potential* pot = a->pot;
-    if (REG_OK && pot->D == RD) return reg_hmc<REG_OK>(a);  // the chain fits the lane's registers
+    // the chain fits the lane's registers: kick-drift-kick/FMA form up to twice the dimension
+    if (REG_OK_KDK && pot->D == RD && (a->flags & PBBI_KDK_FMA) && a->method == PBBI_LEAPFROG)
+        return reg_hmc<REG_OK_KDK, true>(a);
+    if (REG_OK && pot->D == RD) return reg_hmc<REG_OK>(a);
     Scratch ws(*a);
     const size_t slab = (size_t)pot->D * a->N * sizeof(T);
     T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab), *Wg = (T*)ws.get(slab);

@@ -1219,3 +1219,34 @@ def test_rhat_matches_numpy_and_detects_disagreement(P):
     r2 = hmc.rhat(shifted)
     assert np.allclose(r2, rhat_np(shifted.cpu().numpy()), rtol=1e-10)
     assert r2[0] > 2.0 and np.all(np.abs(r2[1:] - 1.0) < 0.05)
+
+
+@pytest.mark.parametrize("D,mass", [(11, False), (24, True), (40, False)])
+def test_custom_potential_kdk_form(P, lib, D, mass):
+    """User potential under PBBI_KDK_FMA (the in-kernel-draw default): D = 11 and 24 run the
+    register-resident kick-drift-kick kernel (q, v, g on chip: twice the dimension of the
+    reference-order variant), D = 40 the workspace kernels; 1e-12 against the oracle, masks equal."""
+    from custom_sources import QUARTIC
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    N, S, L, h, seed = 400, 4, 9, 0.07, 13
+    prm = [1.5, 0.75]
+    pot, op = CustomPotential(D, QUARTIC, prm), orc.pot_custom(QUARTIC, D, prm)
+    m = (1.0 + (np.arange(N) % 4) * 0.5) if mass else None
+    ens = P.Ensemble(D, N)
+    if mass:
+        ens.mass = m.copy()
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, verbose=False)
+    assert hmc.kdk_fma
+    samples, momenta = hmc.getSamples(S, 1.0 / kB, 1.0)
+    q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 0, D, N, 1.0)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 0, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, i, 0, N)
+        _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+        assert np.array_equal(hmc.reject_masks[i], rej)
+        assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
+        q = samples[:, :, i].copy()
+        n_rej += int(rej.sum())
+    assert 0 < n_rej < S * N

@@ -27,7 +27,7 @@ def run(name, pot, D, N, h, L=10, K=10, W=2):
 
     def go(s, it0):
         _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
-                  None, rej.data_ptr(), None, N, N, h, L, s, 0, 7, it0, 0, 1.0, stream)
+                  None, rej.data_ptr(), None, N, N, h, L, s, _lib.KDK_FMA, 7, it0, 0, 1.0, stream)
     go(W, 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -41,7 +41,8 @@ def run(name, pot, D, N, h, L=10, K=10, W=2):
 
 if __name__ == "__main__":
     run("quartic chain (registers)", CustomPotential(16, QUARTIC, [1.0, 0.5]), 16, 262144, 0.05)
-    run("quartic chain (workspace)", CustomPotential(32, QUARTIC, [1.0, 0.5]), 32, 262144, 0.05)
+    run("quartic chain (registers, kick-drift-kick form)", CustomPotential(32, QUARTIC, [1.0, 0.5]), 32, 262144, 0.05)
+    run("quartic chain (workspace)", CustomPotential(48, QUARTIC, [1.0, 0.5]), 48, 131072, 0.05)
     run("quartic chain", CustomPotential(128, QUARTIC, [1.0, 0.5]), 128, 65536, 0.05)
     X, y, lam, prm = logistic_problem(M=256, D=16)
     run("logistic regression M=256", CustomPotential(16, LOGISTIC, prm), 16, 65536, 0.02)
