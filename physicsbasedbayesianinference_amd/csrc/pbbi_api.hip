@@ -40,10 +40,9 @@ int upload(const double* host, size_t n, int dtype, void** dev_out) {
 }
 
 // The workspace-based paths (kernels_big / kernels_stream / user plugins) take their scratch from
-// the device's default stream-ordered pool with hipMallocAsync every iteration.  With the default
-// release threshold (0) the pool hands its memory back to the OS at every synchronisation and the
-// next allocations are real ones -- measured at D = 512 fp64: 19.7 ms per iteration instead of 4.6.
-// Keep freed blocks in the pool instead (once per device).
+// the device's default stream-ordered pool (hipMallocAsync).  With the default release threshold
+// (0) the pool hands its memory back to the OS at every synchronisation and the next call's
+// allocations are real ones again; keep freed blocks in the pool instead (once per device).
 void keep_pool_memory(int device) {
     static bool done[64];
     if (device < 0 || device >= 64 || done[device]) return;
