@@ -289,11 +289,12 @@ class HMC:
                   float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
         sharded = torch.distributed.is_available() and torch.distributed.is_initialized()
         h = float(self.stepSize)
+        run_flags = _lib.KDK_FMA if self.kdk_fma else 0  # the same kernels the sampling run will use
         mu, hbar, log_hbar = np.log(10.0 * h), 0.0, 0.0
         for m in range(1, int(iterations) + 1):
             L = max(1, int(self.simulTime / h))
             _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
-                      sample.data_ptr(), None, None, ratio.data_ptr(), N, N, h, L, 1, 0, seed,
+                      sample.data_ptr(), None, None, ratio.data_ptr(), N, N, h, L, 1, run_flags, seed,
                       (1 << 40) + m, int(chain0), kT, stream)  # counters disjoint from getSamples'
             acc = torch.nan_to_num(torch.clamp(ratio[0].double(), max=1.0), nan=0.0).sum()
             cnt = torch.tensor(float(N), dtype=torch.float64, device=acc.device)
