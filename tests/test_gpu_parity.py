@@ -1056,6 +1056,21 @@ def test_rosenbrock_kdk_fma_form(P, lib, D, N, mass):
         q = samples[:, :, i].copy()  # continue from the device state: compare step by step
         n_rej += int(rej.sum())
     assert n_rej > 0
+    # host-supplied momenta / uniforms through pbbi_hmc_iter with the flag (compat store of p)
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D)
+    p, u = rs.standard_normal((D, N)) * pstd, rs.uniform(size=N)
+    u[::5] = 1.5
+    qd, pd, ud = (as_device(x, 0, np.float64) for x in (q, p, u))
+    md = as_device(m, 0, np.float64) if mass else None
+    qo, po, rj = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0), empty((N,), np.uint8, 0)
+    lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+             md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), None, rj.data_ptr(), N, N, h, L,
+             lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA, stream_ptr(0))
+    q_or, p_or = q.copy(), p.copy()
+    _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L)
+    assert np.array_equal(to_numpy(rj).astype(bool), rej) and rej.sum() >= N // 5
+    assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
 
 
 @pytest.mark.parametrize("kind,D,N,mass", [("diag", 32, 700, False), ("harmonic", 17, 100, True),
