@@ -72,7 +72,7 @@ enum {
      * element-step for the updates, no acceleration array).  Algebraically the reference's
      * velocity-Verlet (src/integrator.py:105-120); results agree to ~1e-13 relative instead of bit
      * for bit, accept masks as before.  Honoured by the two-lane Rosenbrock kernel (config C3) and
-     * by the multi-wave harmonic / diagonal-Gaussian and Rosenbrock kernels (D <= 256); the MFMA kernels always
+     * by the multi-lane / multi-wave harmonic, diagonal-Gaussian and Rosenbrock kernels (D <= 256); the MFMA kernels always
      * integrate this way, the other chain-per-lane kernels ignore it. */
     PBBI_KDK_FMA = 2
 };

@@ -558,7 +558,8 @@ inline bool streams(const pbbi_potential* pot) { return pot->dtype != PBBI_F64 |
 
 int lane_hmc_iter(const IterArgs& a) {
     if (sepn_applies(a)) return sepn_hmc_iter(a);
-    if (rosn_applies(a)) return rosn_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 32 < D <= 256  // PBBI_KDK_FMA, separable, 16 < D <= 256
+    if (rosg_applies(a)) return rosg_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 32 < D <= 128: 4 / 8 lanes of one wave
+    if (rosn_applies(a)) return rosn_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 128 < D <= 256: parts in waves  // PBBI_KDK_FMA, separable, 16 < D <= 256
     if (streams(a.pot)) return stream_hmc_iter(a);
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;

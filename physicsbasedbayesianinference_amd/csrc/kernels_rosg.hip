@@ -1,0 +1,225 @@
+// kernels_rosg.hip -- Rosenbrock, 32 < D <= 128, Leapfrog in the PBBI_KDK_FMA form: G = 4 or 8 LANES
+// PER CHAIN inside one wave (the two-lane kernel of kernels_lane2.hip generalised), gfx950.
+//
+// lane l -> chain c = l % (64/G), part = l / (64/G), dims 16*part + j.  The nearest-neighbour term
+// crosses a part boundary through in-wave shuffles (q_{16(part+1)} comes down from the next part,
+// t_{16 part - 1} comes up from the previous one): no LDS round trip through a workgroup barrier,
+// which is what limits the parts-in-waves kernel (kernels_rosn.hip: 11 barriers per iteration).
+// The price is narrower row segments (64/G chains x 8 B per part) -- measured against
+// kernels_rosn.hip the in-wave form wins at every D it covers: 0.70 vs 0.45 of the HBM roofline at
+// D = 64, 0.51 vs 0.34 at D = 128 (PBBI_ROSG_MAX_D moves the switch for A/B runs).
+//
+// Arithmetic: kernels_lane2.hip's kdk_kick / U_pair / pp_pair (7 fp64 instructions per element-step,
+// state q and the half-step velocity), energies summed over the G parts by an xor butterfly.
+// q, p within 1e-12 of the oracle, accept masks equal (test_rosenbrock_multiwave_kdk covers both).
+#include <cstdlib>
+
+#include "pbbi_buf.h"
+#include "pbbi_internal.h"
+#include "pbbi_rng.h"
+
+namespace {
+
+constexpr int DL = 16;  // dims per lane
+
+struct RosgPrm {
+    const double* q_in;
+    const double* p_in;
+    const double* u_in;
+    const double* mass;
+    double* q_out;
+    double* p_out;
+    double* ratio_out;
+    uint8_t* reject_out;
+    int64_t N, ldn_in, ldn_out;
+    double h, a, b, inv_s, kT, c1, c2, c3;  // c1 = (-4b)/s, c2 = 2/s, c3 = (2b)/s
+    int L, D, flags, rng;
+    uint64_t seed, iter, chain0;
+};
+
+template <int G>
+__device__ __forceinline__ double part_sum(double x) {  // sum over the G lanes of a chain
+    constexpr int CPW = 64 / G;
+#pragma unroll
+    for (int s = CPW; s < 64; s <<= 1) x += __shfl_xor(x, s, 64);
+    return x;
+}
+
+template <int G, bool UNIT, bool FULL>
+__global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
+    constexpr int CPW = 64 / G;  // chains per wave
+    const int lane = threadIdx.x;
+    const int part = lane / CPW, c = lane % CPW;
+    const int64_t n0 = (int64_t)blockIdx.x * CPW;  // block-uniform
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;
+    const int D = prm.D;
+    const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
+    const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vin = 8u * (uint32_t)cc + (uint32_t)(DL * part) * rin;
+    const uint32_t vout = 8u * (uint32_t)cc + (uint32_t)(DL * part) * rout;
+    // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): rows past D read 0 / drop stores
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0, D, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
+    auto exists = [&](int j) { return FULL ? true : DL * part + j < D; };
+    auto has_next = [&](int j) {  // dim 16*part + j has a right neighbour
+        if constexpr (FULL) return j + 1 < DL ? true : part + 1 < G;
+        return DL * part + j + 1 < D;
+    };
+
+    double q[DL], v[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
+    const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    auto draw = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // this part's group of 16 dims: blocks (part<<2)|r
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+        }
+    };
+    auto load_p = [&]() {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = buf_load<double>(bp, vin, (uint32_t)j * rin);
+    };
+    if (prm.rng) draw(); else load_p();
+
+    const double nc1 = -prm.c1, nc2 = -prm.c2, c2a = prm.c2 * prm.a, nc3 = -prm.c3;
+    // value held by the same chain's next / previous part (garbage in the last / first part: unused)
+    auto from_next = [&](double x) { return __shfl_down(x, CPW, 64); };
+    auto from_prev = [&](double x) { return __shfl_up(x, CPW, 64); };
+    // H = 0.5 p.p / m + (sum b t^2 + sum (a - q)^2) / s, summed over the chain's parts
+    auto hamiltonian = [&]() {
+        const double q_ext = from_next(q[0]);
+        double pp = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            const double t = fma(-q[j], q[j], qn);
+            const double r = prm.a - q[j];
+            const double n1 = fma(prm.b * t, t, s1), n2 = fma(r, r, s2);
+            const bool hn = has_next(j);
+            s1 = hn ? n1 : s1;
+            s2 = hn ? n2 : s2;
+            pp = fma(v[j], v[j], pp);
+        }
+        return 0.5 * part_sum<G>(pp) / m + part_sum<G>(s1 + s2) * prm.inv_s;
+    };
+    // v_j += kk * (-g_j): kernels_lane2.hip::kdk_kick with the boundary terms from the neighbour parts
+    auto kick = [&](double kk) {
+        const double q_ext = from_next(q[0]);
+        const double kn3 = kk * nc3;
+        const double t15 = fma(-q[DL - 1], q[DL - 1], q_ext);
+        const double t_prev = from_prev(has_next(DL - 1) ? t15 : 0.0);
+        const double v0 = fma(kn3, t_prev, v[0]);
+        v[0] = (part > 0 && exists(0)) ? v0 : v[0];
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            const double t = fma(-q[j], q[j], qn);
+            const double nfirst = fma(nc1 * q[j], t, fma(nc2, q[j], c2a));
+            const bool hn = has_next(j);
+            const double vj = fma(nfirst, kk, v[j]);
+            v[j] = hn ? vj : v[j];
+            if (j + 1 < DL) {
+                const double vn = fma(kn3, t, v[(j + 1) & (DL - 1)]);
+                v[(j + 1) & (DL - 1)] = hn ? vn : v[(j + 1) & (DL - 1)];
+            }
+        }
+    };
+
+    const double oldH = hamiltonian();
+    // ---- Leapfrog, kick-drift-kick: vh = v + a0 h/2;  L x { q += vh h; vh += a(q) h }, last kick half
+    const double h = prm.h, hm = UNIT ? h : h / m, hhm = 0.5 * hm;
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
+    }
+    if (prm.L > 0) {
+        kick(hhm);
+        for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
+            kick((s + 1 < prm.L) ? hm : hhm);
+        }
+    }
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+    const double newH = hamiltonian();
+    const double ratio = exp(oldH - newH);  // src/HMC.py:115
+    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < DL; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+                load_p();
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) buf_store(bqo, vout, (uint32_t)j * rout, q[j]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
+        }
+        if (part == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+        }
+    }
+}
+
+template <int G>
+void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
+    constexpr int CPW = 64 / G;
+    const dim3 grid((unsigned)((a.N + CPW - 1) / CPW)), block(64);
+#define ROSG_LAUNCH(U_)                                                                          \
+    {                                                                                            \
+        if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true>), grid, block, 0, a.stream, prm);  \
+        else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false>), grid, block, 0, a.stream, prm);      \
+    }
+    if (a.mass) ROSG_LAUNCH(false) else ROSG_LAUNCH(true)
+#undef ROSG_LAUNCH
+}
+
+}  // namespace
+
+// true if this path takes the call: Rosenbrock, fp64, Leapfrog, PBBI_KDK_FMA, 32 < D <= PBBI_ROSG_MAX_D
+bool rosg_applies(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    static const int max_d = getenv("PBBI_ROSG_MAX_D") ? atoi(getenv("PBBI_ROSG_MAX_D")) : 128;
+    return pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 && a.method == PBBI_LEAPFROG &&
+           (a.flags & PBBI_KDK_FMA) != 0 && pot->D > 32 && pot->D <= max_d && pot->D <= 128 &&
+           (int64_t)pot->D * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
+}
+
+int rosg_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (a.N == 0) return PBBI_OK;
+    const double inv_s = 1.0 / pot->s;
+    RosgPrm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+                (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
+                a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, inv_s, a.kT,
+                (-4.0 * pot->b) * inv_s, 2.0 * inv_s, (2.0 * pot->b) * inv_s, a.L, pot->D, a.flags,
+                a.rng, a.seed, a.iter, a.chain0};
+    if (pot->D <= 64) launch<4>(a, prm, pot->D == 64);
+    else launch<8>(a, prm, pot->D == 128);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}

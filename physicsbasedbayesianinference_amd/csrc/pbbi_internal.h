@@ -164,6 +164,9 @@ int sepn_hmc_iter(const IterArgs& a);
 // Rosenbrock, 32 < D <= 256, PBBI_KDK_FMA, same layout with boundary exchange through LDS, kernels_rosn.hip
 bool rosn_applies(const IterArgs& a);
 int rosn_hmc_iter(const IterArgs& a);
+// Rosenbrock, 32 < D <= 64 (128), PBBI_KDK_FMA: 4 (8) lanes of one wave per chain, kernels_rosg.hip
+bool rosg_applies(const IterArgs& a);
+int rosg_hmc_iter(const IterArgs& a);
 // the same potentials for D > 64 and for fp32: chain state in a device workspace, kernels_stream.hip
 int stream_hmc_iter(const IterArgs& a);
 int stream_integrate(const IntegrateArgs& a);

@@ -1120,10 +1120,12 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
 
 
 @pytest.mark.parametrize("D,N,mass", [(48, 500, False), (64, 333, True), (100, 130, False),
-                                      (128, 1000, False), (256, 70, True), (33, 64, False)])
+                                      (128, 1000, False), (256, 70, True), (33, 64, False),
+                                      (144, 200, True), (200, 64, False)])
 def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
-    """kernels_rosn.hip: Rosenbrock at 32 < D <= 256 with a chain's 16-dim parts in different waves
-    (boundary values exchanged through LDS), PBBI_KDK_FMA form: q, p within 1e-12 of the oracle's
+    """Rosenbrock at 32 < D <= 256 under PBBI_KDK_FMA: kernels_rosg.hip up to D = 128 (4 / 8 lanes of
+    one wave per chain, in-wave boundary exchange) and kernels_rosn.hip above (a chain's 16-dim
+    parts in different waves, boundary values through LDS): q, p within 1e-12 of the oracle's
     velocity-Verlet, accept masks equal, both RNG modes."""
     S, L, h, seed = 4, 8, 0.03, 31
     pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
