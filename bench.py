@@ -141,8 +141,20 @@ def main_c3(args):
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
         "roofline": {"bound": "hbm", "kernel": "k_ros2_hmc<unit mass, D=32> (two lanes per chain)",
                      "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": c3_traffic(args),
                      "launch_ms": ks * 1e3}}))
+
+
+def c3_traffic(args):
+    """HBM bytes per launch of the C3 kernel from the committed PMC passes (profiles/r01_pmc_c3.json:
+    separate FETCH_SIZE / WRITE_SIZE runs of tools/profile_c3.py, kick-drift-kick form, 262144 chains)."""
+    if args.exact_order or args.chains != N_PER_GPU:
+        return None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_c3.json")) as f:
+            return json.load(f)["derived"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main_stream(args):

@@ -17,6 +17,6 @@ samples = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 mom = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 rej = torch.empty((S, N), dtype=torch.uint8, device="cuda")
 _lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, samples.data_ptr(), mom.data_ptr(),
-          rej.data_ptr(), None, N, N, 0.01, L, S, 1, 1, 0, 0, 1.0, None)
+          rej.data_ptr(), None, N, N, 0.01, L, S, _lib.COMPAT_P_FROM_OLDQ | _lib.KDK_FMA, 1, 0, 0, 1.0, None)
 torch.cuda.synchronize()
 print("ok", float(rej.float().mean()))
