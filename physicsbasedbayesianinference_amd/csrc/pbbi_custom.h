@@ -153,6 +153,41 @@ __device__ __forceinline__ void trajectory(const Chain& c, T m, T h, int L) {
     }
 }
 
+// PBBI_KDK_FMA on the workspace: vh = v + a0 h/2;  L x { q += vh h; vh += a(q) h }, last kick half.
+// The kick of step s and the drift of step s+1 share one sweep (v, g, q in; v, q out): 5 accesses
+// per element-step beside the user's gradient (reference order: 9), no acceleration array.
+template <bool UNIT>
+__device__ __forceinline__ void trajectory_kdk(const Chain& c, T m, T h, int L) {
+    if (L <= 0) return;
+    const T hm = UNIT ? h : h / m, hhm = T(0.5) * hm;
+    c.gradient();
+    for (int s = 0; s < L; ++s) {  // kick with the gradient of the current q, then drift
+        const T kk = (s == 0) ? hhm : hm;
+        for (int j0 = 0; j0 < c.D; j0 += CH) {
+            T g[CH], v[CH], q[CH];
+            load_rows<CH>(c.g, c.ld, j0, c.D, g);
+            load_rows<CH>(c.v, c.ld, j0, c.D, v);
+            load_rows<CH>(c.q, c.ld, j0, c.D, q);
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (j0 + k < c.D) {
+                    const T vn = fma(-g[k], kk, v[k]);
+                    c.v[(int64_t)(j0 + k) * c.ld] = vn;
+                    c.q[(int64_t)(j0 + k) * c.ld] = fma(vn, h, q[k]);
+                }
+        }
+        c.gradient();
+    }
+    for (int j0 = 0; j0 < c.D; j0 += CH) {  // closing half kick
+        T g[CH], v[CH];
+        load_rows<CH>(c.g, c.ld, j0, c.D, g);
+        load_rows<CH>(c.v, c.ld, j0, c.D, v);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (j0 + k < c.D) c.v[(int64_t)(j0 + k) * c.ld] = fma(-g[k], hhm, v[k]);
+    }
+}
+
 template <int METHOD>
 __device__ __forceinline__ T final_v(T q, T v_or_qpast, T h) {
     if constexpr (METHOD == PBBI_STORMER_VERLET) return (q - v_or_qpast) / h;  // :160
@@ -177,7 +212,7 @@ struct HmcPrm {
     T *Wq, *Wv, *Wa, *Wg;
 };
 
-template <int METHOD, bool UNIT>
+template <int METHOD, bool UNIT, bool KDK = false>
 __global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
     const int64_t n = (int64_t)blockIdx.x * SB + threadIdx.x;
     if (n >= prm.N) return;
@@ -218,7 +253,8 @@ __global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
             if (j0 + k < D) c.q[(int64_t)(j0 + k) * ld] = q[k];
     }
     const T oldH = T(0.5) * pp / m + c.potential();  // src/HMC.py:100-102
-    trajectory<METHOD, UNIT>(c, m, prm.h, prm.L);
+    if constexpr (KDK) trajectory_kdk<UNIT>(c, m, prm.h, prm.L);
+    else trajectory<METHOD, UNIT>(c, m, prm.h, prm.L);
     T pp1 = T(0);
     const T* vsrc = METHOD == PBBI_STORMER_VERLET ? c.a : c.v;
     for (int j0 = 0; j0 < D; j0 += CH) {
@@ -634,10 +670,19 @@ int pbbi_plugin_hmc_iter(const IterArgs* a) {
                (T*)a->q_out, (T*)a->p_out, (T*)a->ratio_out, a->reject_out,
                a->N, a->ldn_in, a->ldn_out, (T)a->h, a->L, pot->D, a->flags, a->rng,
                a->seed, a->iter, a->chain0, a->kT, (const T*)pot->d_params, Wq, Wv, Wa, Wg};
-    with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
-        hipLaunchKernelGGL((k_custom_hmc<decltype(meth)::value, decltype(unit)::value>),
-                           grid_for(a->N), dim3(SB), 0, a->stream, prm);
-    });
+    if ((a->flags & PBBI_KDK_FMA) && a->method == PBBI_LEAPFROG) {
+        if (a->mass == nullptr)
+            hipLaunchKernelGGL((k_custom_hmc<PBBI_LEAPFROG, true, true>), grid_for(a->N), dim3(SB), 0,
+                               a->stream, prm);
+        else
+            hipLaunchKernelGGL((k_custom_hmc<PBBI_LEAPFROG, false, true>), grid_for(a->N), dim3(SB), 0,
+                               a->stream, prm);
+    } else {
+        with_method_unit(a->method, a->mass == nullptr, [&](auto meth, auto unit) {
+            hipLaunchKernelGGL((k_custom_hmc<decltype(meth)::value, decltype(unit)::value>),
+                               grid_for(a->N), dim3(SB), 0, a->stream, prm);
+        });
+    }
     return (int)hipGetLastError();
 }
 
