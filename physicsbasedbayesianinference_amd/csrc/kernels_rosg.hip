@@ -204,8 +204,9 @@ void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
 bool rosg_applies(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     static const int max_d = getenv("PBBI_ROSG_MAX_D") ? atoi(getenv("PBBI_ROSG_MAX_D")) : 128;
+    static const int min_d = getenv("PBBI_ROSG_MIN_D") ? atoi(getenv("PBBI_ROSG_MIN_D")) : 33;
     return pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 && a.method == PBBI_LEAPFROG &&
-           (a.flags & PBBI_KDK_FMA) != 0 && pot->D > 32 && pot->D <= max_d && pot->D <= 128 &&
+           (a.flags & PBBI_KDK_FMA) != 0 && pot->D >= min_d && pot->D > 16 && pot->D <= max_d && pot->D <= 128 &&
            (int64_t)pot->D * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
 }
 
@@ -218,7 +219,8 @@ int rosg_hmc_iter(const IterArgs& a) {
                 a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, inv_s, a.kT,
                 (-4.0 * pot->b) * inv_s, 2.0 * inv_s, (2.0 * pot->b) * inv_s, a.L, pot->D, a.flags,
                 a.rng, a.seed, a.iter, a.chain0};
-    if (pot->D <= 64) launch<4>(a, prm, pot->D == 64);
+    if (pot->D <= 32) launch<2>(a, prm, pot->D == 32);
+    else if (pot->D <= 64) launch<4>(a, prm, pot->D == 64);
     else launch<8>(a, prm, pot->D == 128);
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
