@@ -67,13 +67,15 @@ enum {
     /* reproduce src/HMC.py:176: a rejected chain's stored momentum is its OLD POSITION.
      * Without the flag the stored momentum of a rejected chain is the drawn momentum. */
     PBBI_COMPAT_P_FROM_OLDQ = 1,
-    /* Leapfrog only, opt-in throughput form: integrate in kick-drift-kick form with fused
+    /* Opt-in throughput form: integrate in kick-drift-kick form with fused
      * multiply-adds (state q and the half-step velocity; 2 instead of 7 fp64 instructions per
      * element-step for the updates, no acceleration array).  Algebraically the reference's
      * velocity-Verlet (src/integrator.py:105-120); results agree to ~1e-13 relative instead of bit
      * for bit, accept masks as before.  Honoured by the two-lane Rosenbrock kernel (config C3) and
      * by the multi-lane / multi-wave harmonic, diagonal-Gaussian and Rosenbrock kernels (D <= 256); the MFMA kernels always
-     * integrate this way, the other chain-per-lane kernels ignore it. */
+     * integrate this way, the other chain-per-lane kernels ignore it.  Stormer-Verlet under the flag
+     * is the same recurrence without the closing half kick and with one more drift (honoured by the
+     * separable kernel up to D = 256 and the in-wave Rosenbrock kernel up to D = 128). */
     PBBI_KDK_FMA = 2
 };
 enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2 };

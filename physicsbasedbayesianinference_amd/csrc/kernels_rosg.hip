@@ -45,7 +45,7 @@ __device__ __forceinline__ double part_sum(double x) {  // sum over the G lanes 
     return x;
 }
 
-template <int G, bool UNIT, bool FULL>
+template <int G, bool UNIT, bool FULL, int METHOD>
 __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
     constexpr int CPW = 64 / G;  // chains per wave
     const int lane = threadIdx.x;
@@ -141,13 +141,26 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    if (prm.L > 0) {
+    if constexpr (METHOD == PBBI_LEAPFROG) {
+        if (prm.L > 0) {
+            kick(hhm);
+            for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+                for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
+                kick((s + 1 < prm.L) ? hm : hhm);
+            }
+        }
+    } else {
+        // Stormer-Verlet (src/integrator.py:142-163) with d = q_n - q_{n-1} = vh h: the same recurrence
+        // without the closing half kick and with one more drift; the final velocity is vh
         kick(hhm);
         for (int s = 0; s < prm.L; ++s) {
 #pragma unroll
             for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
-            kick((s + 1 < prm.L) ? hm : hhm);
+            kick(hm);
         }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
     }
     if constexpr (!UNIT) {
 #pragma unroll
@@ -189,12 +202,16 @@ template <int G>
 void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
     constexpr int CPW = 64 / G;
     const dim3 grid((unsigned)((a.N + CPW - 1) / CPW)), block(64);
-#define ROSG_LAUNCH(U_)                                                                          \
-    {                                                                                            \
-        if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true>), grid, block, 0, a.stream, prm);  \
-        else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false>), grid, block, 0, a.stream, prm);      \
+#define ROSG_LAUNCH(U_, M_)                                                                          \
+    {                                                                                                \
+        if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true, M_>), grid, block, 0, a.stream, prm);  \
+        else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false, M_>), grid, block, 0, a.stream, prm);      \
     }
-    if (a.mass) ROSG_LAUNCH(false) else ROSG_LAUNCH(true)
+    if (a.method == PBBI_LEAPFROG) {
+        if (a.mass) ROSG_LAUNCH(false, PBBI_LEAPFROG) else ROSG_LAUNCH(true, PBBI_LEAPFROG)
+    } else {
+        if (a.mass) ROSG_LAUNCH(false, PBBI_STORMER_VERLET) else ROSG_LAUNCH(true, PBBI_STORMER_VERLET)
+    }
 #undef ROSG_LAUNCH
 }
 
@@ -205,8 +222,11 @@ bool rosg_applies(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     static const int max_d = getenv("PBBI_ROSG_MAX_D") ? atoi(getenv("PBBI_ROSG_MAX_D")) : 128;
     static const int min_d = getenv("PBBI_ROSG_MIN_D") ? atoi(getenv("PBBI_ROSG_MIN_D")) : 33;
-    return pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 && a.method == PBBI_LEAPFROG &&
-           (a.flags & PBBI_KDK_FMA) != 0 && pot->D >= min_d && pot->D > 16 && pot->D <= max_d && pot->D <= 128 &&
+    // Leapfrog at D <= 32 belongs to kernels_lane2.hip; Stormer-Verlet has no other kick-drift-kick
+    // kernel, so it comes here from D = 17 on (two lanes per chain)
+    const int lo = a.method == PBBI_LEAPFROG ? min_d : 17;
+    return pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 &&
+           (a.flags & PBBI_KDK_FMA) != 0 && pot->D >= lo && pot->D > 16 && pot->D <= max_d && pot->D <= 128 &&
            (int64_t)pot->D * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
 }
 

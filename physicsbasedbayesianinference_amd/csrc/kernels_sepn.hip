@@ -1,5 +1,5 @@
 // kernels_sepn.hip -- harmonic / diagonal-Gaussian potentials, 16 < D <= 256, Leapfrog in the
-// PBBI_KDK_FMA form: a chain's dimensions are cut into 16-dim PARTS held by different WAVES of one
+// PBBI_KDK_FMA form (Stormer-Verlet likewise, as the same recurrence): a chain's dimensions are cut into 16-dim PARTS held by different WAVES of one
 // workgroup, gfx950.
 //
 // With one chain per lane (kernels_lane.hip) a D = 64 chain needs 192 VGPRs of state and runs one
@@ -45,7 +45,7 @@ struct SepPrm {
 
 // FULL: D is a multiple of 16, every dim of every part exists: no guards (as scalar branches they
 // put an s_waitcnt between consecutive loads / stores)
-template <bool UNIT, bool FULL>
+template <bool UNIT, bool FULL, int METHOD>
 __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     __shared__ double dH[MAXG][64];
     const int c = threadIdx.x & 63;
@@ -121,10 +121,29 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    if (prm.L > 0) {
+    if constexpr (METHOD == PBBI_LEAPFROG) {
+        if (prm.L > 0) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) v[j] = fma(pr[j] * q[j], nhh, v[j]);
+            for (int s = 0; s + 1 < prm.L; ++s) {
+#pragma unroll
+                for (int j = 0; j < DL; ++j) {
+                    q[j] = fma(v[j], h, q[j]);
+                    v[j] = fma(pr[j] * q[j], nhm, v[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                q[j] = fma(v[j], h, q[j]);
+                v[j] = fma(pr[j] * q[j], nhh, v[j]);
+            }
+        }
+    } else {
+        // Stormer-Verlet (src/integrator.py:142-163) with d = q_n - q_{n-1} = vh h: the same recurrence
+        // without the closing half kick and with one more drift; the final velocity is vh
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = fma(pr[j] * q[j], nhh, v[j]);
-        for (int s = 0; s + 1 < prm.L; ++s) {
+        for (int s = 0; s < prm.L; ++s) {
 #pragma unroll
             for (int j = 0; j < DL; ++j) {
                 q[j] = fma(v[j], h, q[j]);
@@ -132,10 +151,7 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < DL; ++j) {
-            q[j] = fma(v[j], h, q[j]);
-            v[j] = fma(pr[j] * q[j], nhh, v[j]);
-        }
+        for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
     }
     if constexpr (!UNIT) {
 #pragma unroll
@@ -188,8 +204,7 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
 bool sepn_applies(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     return (pot->kind == KIND_HARMONIC || pot->kind == KIND_GAUSS_DIAG) && pot->dtype == PBBI_F64 &&
-           a.method == PBBI_LEAPFROG && (a.flags & PBBI_KDK_FMA) != 0 && pot->D > 16 &&
-           pot->D <= DL * MAXG &&
+           (a.flags & PBBI_KDK_FMA) != 0 && pot->D > 16 && pot->D <= DL * MAXG &&
            (int64_t)DL * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
 }
 
@@ -203,13 +218,19 @@ int sepn_hmc_iter(const IterArgs& a) {
     const int G = (pot->D + DL - 1) / DL;
     const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
     const bool full = (pot->D % DL == 0);
-    if (a.mass) {
-        if (full) hipLaunchKernelGGL((k_sep_hmc<false, true>), grid, block, 0, a.stream, prm);
-        else hipLaunchKernelGGL((k_sep_hmc<false, false>), grid, block, 0, a.stream, prm);
-    } else {
-        if (full) hipLaunchKernelGGL((k_sep_hmc<true, true>), grid, block, 0, a.stream, prm);
-        else hipLaunchKernelGGL((k_sep_hmc<true, false>), grid, block, 0, a.stream, prm);
+#define SEP_LAUNCH(U_, F_)                                                                              \
+    {                                                                                                   \
+        if (a.method == PBBI_LEAPFROG)                                                                  \
+            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_LEAPFROG>), grid, block, 0, a.stream, prm);      \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_STORMER_VERLET>), grid, block, 0, a.stream, prm);\
     }
+    if (a.mass) {
+        if (full) SEP_LAUNCH(false, true) else SEP_LAUNCH(false, false)
+    } else {
+        if (full) SEP_LAUNCH(true, true) else SEP_LAUNCH(true, false)
+    }
+#undef SEP_LAUNCH
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

@@ -1077,7 +1077,8 @@ def test_rosenbrock_kdk_fma_form(P, lib, D, N, mass):
                                            ("diag", 64, 333, True), ("diag", 50, 64, False),
                                            ("harmonic", 128, 1000, False), ("diag", 100, 257, True),
                                            ("diag", 256, 130, False), ("harmonic", 241, 70, True)])
-def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
+@pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
+def test_separable_multilane_kdk(P, lib, kind, D, N, mass, method):
     """kernels_sepn.hip: harmonic / diagonal Gaussian, a chain's 16-dim parts in different waves of
     one workgroup, PBBI_KDK_FMA form (both RNG modes): q, p within 1e-12 of the oracle's
     velocity-Verlet, masks equal."""
@@ -1088,8 +1089,8 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
     ens = P.Ensemble(D, N)
     if mass:
         ens.mass = m.copy()
-    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=True,
-                compat=False, verbose=False)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, method=method, rng="philox", seed=seed,
+                kdk_fma=True, compat=False, verbose=False)
     samples, momenta = hmc.getSamples(S, 1.0 / kB, 1.0, chain0=9)
     q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 9, D, N, 1.0)
     pstd = np.sqrt(m) if mass else np.ones(N)
@@ -1097,7 +1098,7 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
     for i in range(S):
         p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 9, D, N, 1.0, pstd)
         u = device_uniform(lib, seed, i, 9, N)
-        r_or, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=0)
+        r_or, rej = orc.hmc_iter(op, method, q, p, u, m, h, L, compat=0)
         assert np.array_equal(hmc.reject_masks[i], rej)
         assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
         assert np.max(np.abs(np.log(hmc.ratios[i]) - np.log(r_or))) < 1e-9
@@ -1110,11 +1111,11 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
     qd, pd, ud = (as_device(x, 0, np.float64) for x in (q, p, u))
     md = as_device(m, 0, np.float64) if mass else None
     qo, po, rj = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0), empty((N,), np.uint8, 0)
-    lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+    lib.call("pbbi_hmc_iter", pot.handle, orc.METHODS[method], qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
              md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), None, rj.data_ptr(), N, N, h, L,
              lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA, stream_ptr(0))
     q_or, p_or = q.copy(), p.copy()
-    _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L)
+    _, rej = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L)
     assert np.array_equal(to_numpy(rj).astype(bool), rej)
     assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
 
@@ -1123,6 +1124,17 @@ def test_separable_multilane_kdk(P, lib, kind, D, N, mass):
                                       (128, 1000, False), (256, 70, True), (33, 64, False),
                                       (144, 200, True), (200, 64, False)])
 def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
+    _rosenbrock_kdk_case(P, lib, D, N, mass, "Leapfrog")
+
+
+@pytest.mark.parametrize("D,N,mass", [(20, 100, False), (32, 300, True), (64, 200, False), (100, 70, True)])
+def test_rosenbrock_kdk_stormer_verlet(P, lib, D, N, mass):
+    """Stormer-Verlet under PBBI_KDK_FMA on kernels_rosg.hip (2 / 4 / 8 lanes per chain): the same
+    recurrence without the closing half kick and with one more drift."""
+    _rosenbrock_kdk_case(P, lib, D, N, mass, "Stormer-Verlet")
+
+
+def _rosenbrock_kdk_case(P, lib, D, N, mass, method):
     """Rosenbrock at 32 < D <= 256 under PBBI_KDK_FMA: kernels_rosg.hip up to D = 128 (4 / 8 lanes of
     one wave per chain, in-wave boundary exchange) and kernels_rosn.hip above (a chain's 16-dim
     parts in different waves, boundary values through LDS): q, p within 1e-12 of the oracle's
@@ -1133,8 +1145,8 @@ def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
     ens = P.Ensemble(D, N)
     if mass:
         ens.mass = m.copy()
-    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=True,
-                verbose=False)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, method=method, rng="philox", seed=seed,
+                kdk_fma=True, verbose=False)
     samples, momenta = hmc.getSamples(S, 1.0 / kB, 0.3, chain0=3)
     q = device_normal(lib, seed, lib.STREAM_POSITION, 0, 3, D, N, 0.3)
     pstd = np.sqrt(m) if mass else np.ones(N)
@@ -1142,7 +1154,7 @@ def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
     for i in range(S):
         p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 3, D, N, 1.0, pstd)
         u = device_uniform(lib, seed, i, 3, N)
-        r_or, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+        r_or, rej = orc.hmc_iter(op, method, q, p, u, m, h, L)
         assert np.array_equal(hmc.reject_masks[i], rej)
         assert scaled_err(samples[:, :, i], q) <= 1e-12 and scaled_err(momenta[:, :, i], p) <= 1e-12
         fin = np.isfinite(r_or) & (r_or > 0)
@@ -1158,11 +1170,11 @@ def test_rosenbrock_multiwave_kdk(P, lib, D, N, mass):
         qd, pd, ud = (as_device(x, 0, np.float64) for x in (q, p, u))
         md = as_device(m, 0, np.float64) if mass else None
         qo, po, rj = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0), empty((N,), np.uint8, 0)
-        lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+        lib.call("pbbi_hmc_iter", pot.handle, orc.METHODS[method], qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
                  md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), None, rj.data_ptr(), N, N,
                  h, Lx, lib.KDK_FMA, stream_ptr(0))
         q_or, p_or = q.copy(), p.copy()
-        _, rej = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, Lx, compat=0)
+        _, rej = orc.hmc_iter(op, method, q_or, p_or, u, m, h, Lx, compat=0)
         assert np.array_equal(to_numpy(rj).astype(bool), rej)
         assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
 
