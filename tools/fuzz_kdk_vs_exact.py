@@ -21,6 +21,7 @@ for it in range(cases):
     N = int(rs.choice([1, rs.randint(2, 64), rs.randint(64, 700)]))
     L = int(rs.choice([0, 1, 2, 7, 20]))
     mass = bool(rs.randint(2))
+    method = int(rs.randint(2))  # 0 Leapfrog, 1 Stormer-Verlet
     if kind == "diag":
         pot = P.GaussianDiag(rs.standard_normal(D), prec=rs.uniform(0.5, 2, D), const=0.1)
         h, sc = 0.3, 1.0
@@ -38,7 +39,7 @@ for it in range(cases):
     for flags in (lib.COMPAT_P_FROM_OLDQ, lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA):
         qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
         ro, rj = empty((N,), np.float64, 0), empty((N,), np.uint8, 0)
-        lib.call("pbbi_hmc_iter", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+        lib.call("pbbi_hmc_iter", pot.handle, method, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
                  m.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), ro.data_ptr(), rj.data_ptr(),
                  N, N, h, L, flags, stream_ptr(0))
         torch.cuda.synchronize()
@@ -51,7 +52,7 @@ for it in range(cases):
     worst = max(worst, err)
     if not ok:
         bad += 1
-        print("MISMATCH", kind, "D", D, "N", N, "L", L, "mass", mass, "err", err, "log-ratio", lr,
+        print("MISMATCH", kind, "method", method, "D", D, "N", N, "L", L, "mass", mass, "err", err, "log-ratio", lr,
               "masks differ", int((j0 != j1).sum()), flush=True)
 print(f"{cases} cases, {bad} mismatches, worst scaled error {worst:.2e}")
 sys.exit(1 if bad else 0)
