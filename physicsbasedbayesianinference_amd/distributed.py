@@ -17,7 +17,7 @@ Reproducibility across shardings:
 import numpy as np
 from scipy.constants import k as boltzmannConst
 
-__all__ = ["shard_bounds", "HostStream", "gather_samples", "get_samples_sharded"]
+__all__ = ["ensemble_weights", "shard_bounds", "HostStream", "gather_samples", "get_samples_sharded"]
 
 
 def shard_bounds(numParticles, rank, world):
@@ -89,6 +89,29 @@ def gather_samples(local_sdn, group=None):
     if all(n == Nmax for n in all_sizes):
         return recv.permute(1, 2, 0, 3).reshape(S, D, world * Nmax)
     return torch.cat([recv[r, :, :, :all_sizes[r]] for r in range(world)], dim=2)
+
+
+def ensemble_weights(H_local, beta=1.0, group=None):
+    """Normalised canonical weights of a sharded ensemble from the per-chain Hamiltonians
+    (pbbi_energy / HMC.getWeights give H and exp(-H); src/HMC.py:86-104):
+        w_n = exp(-beta (H_n - H_min)) / Z,   Z = sum over ALL ranks' chains
+    with the shift by the global minimum so that exp never underflows.  The first cross-chain
+    reductions of the path: one all-reduce(MIN) and one all-reduce(SUM) of a scalar each (RCCL on
+    CUDA tensors, gloo on CPU tensors); without a process group the sums are local.
+    Returns (w_local, log_Z) with log_Z = log sum_n exp(-beta H_n)."""
+    import torch
+    dist = _dist()
+    H = torch.as_tensor(H_local, dtype=torch.float64)
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    hmin = torch.min(H).reshape(1) if H.numel() else torch.full((1,), float("inf"), dtype=torch.float64,
+                                                                  device=H.device)
+    if sharded:
+        dist.all_reduce(hmin, op=dist.ReduceOp.MIN, group=group)
+    e = torch.exp(-beta * (H - hmin))
+    z = e.sum().reshape(1)
+    if sharded:
+        dist.all_reduce(z, op=dist.ReduceOp.SUM, group=group)
+    return e / z, float(torch.log(z) - beta * hmin)
 
 
 def get_samples_sharded(potential, numDimensions, numParticles, simulTime, stepSize, numSamples,

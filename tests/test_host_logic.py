@@ -171,6 +171,12 @@ full = gather_samples(torch.from_numpy(s_loc)).numpy()
 q = orc.philox_normal(seed, orc.STREAM_POSITION, 0, 0, D, N)
 s_ref, _, _, _ = orc.hmc_run_philox(pot, "Leapfrog", q, None, h, L, S, seed=seed, chain0=0)
 assert np.array_equal(full, s_ref), "philox sharding differs"
+# --- ensemble weights: all-reduce(MIN) + all-reduce(SUM) == the single-process normalisation
+from physicsbasedbayesianinference_amd.distributed import ensemble_weights
+H = np.random.RandomState(5).standard_normal(N) * 30.0 + 800.0          # exp(-H) underflows unshifted
+w_loc, logZ = ensemble_weights(torch.from_numpy(H[lo:hi].copy()))
+w_ref = np.exp(-(H - H.min())); Z = w_ref.sum(); w_ref /= Z
+assert np.allclose(w_loc.numpy(), w_ref[lo:hi], rtol=1e-13) and abs(logZ - (np.log(Z) - H.min())) < 1e-10
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
