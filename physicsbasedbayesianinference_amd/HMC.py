@@ -130,7 +130,7 @@ class HMC:
 
     # ------------------------------------------------------------------ sampling
     def getSamples(self, numSamples, temperature, qStd, rng=None, seed=None, device_output=False,
-                   chain0=0, iter0=0, host_stream=None):
+                   chain0=0, iter0=0, host_stream=None, jitter=0.0):
         """HMC.getSamples (src/HMC.py:123-183): returns (samples_hmc, momentum_hmc), each
         (D, N, numSamples) with the sample index fastest.
 
@@ -139,7 +139,11 @@ class HMC:
         *views* of the (S, D, N) device slabs (no transpose pass, no D2H copy).
         chain0 / iter0 offset the Philox counters (ensemble sharding / resuming);
         host_stream (distributed.HostStream) makes rng="numpy" keep only this shard's
-        columns of the global NumPy stream.
+        columns of the global NumPy stream.  jitter in (0, 1) (rng="philox" only) draws the number
+        of leapfrog steps of every ITERATION uniformly from [L(1-jitter), L(1+jitter)] (one value
+        for the whole ensemble, from a host stream seeded by `seed`, identical on every shard): a
+        fixed trajectory length leaves modes with omega*T near k*pi unmixed; the mixture of
+        trajectory lengths is still a valid HMC kernel.
         """
         pot = self._pot
         ens = self.ensemble
@@ -191,10 +195,22 @@ class HMC:
             q_state = empty((D, N), dt, dev)
             _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D,
                       N, N, float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
-            _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
-                      mptr, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
-                      ratio.data_ptr(), N, N, h, L, S, flags, seed, int(iter0), int(chain0), kT,
-                      stream)
+            if jitter and S > 0:
+                if not 0.0 < jitter < 1.0:
+                    raise ValueError("jitter must be in (0, 1)")
+                u = np.random.RandomState((seed + 0x5EED) % (2 ** 32)).uniform(size=int(iter0) + S)
+                steps = np.maximum(1, np.rint(L * (1.0 + jitter * (2.0 * u - 1.0)))).astype(int)
+                self.numSteps_used = steps[int(iter0):]
+                for i in range(S):
+                    _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                              mptr, samples[i].data_ptr(), momenta[i].data_ptr(), reject[i].data_ptr(),
+                              ratio[i].data_ptr(), N, N, h, int(steps[int(iter0) + i]), 1, flags, seed,
+                              int(iter0) + i, int(chain0), kT, stream)
+            else:
+                _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                          mptr, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
+                          ratio.data_ptr(), N, N, h, L, S, flags, seed, int(iter0), int(chain0), kT,
+                          stream)
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
 

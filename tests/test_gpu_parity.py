@@ -1320,3 +1320,25 @@ def test_momentum_scale_follows_temperature(P, lib, case):
         tol = 1e-13 if case in ("sepn_diag64",) else 0.0   # x = q - mu, q = x + mu round trip
         assert np.max(np.abs(samples[:, :, i] - q0)) <= tol
     assert not hmc.reject_masks.any() and np.all(hmc.ratios == 1.0)
+
+
+def test_trajectory_length_jitter_removes_resonance(P):
+    """A fixed trajectory length T leaves the modes with omega*T near k*pi unmixed (here: one
+    eigen-direction with omega*T = pi exactly: q -> -q every iteration); jitter of the step count
+    per iteration mixes it.  Bayesian-linear-regression-like posterior, chains started at 0."""
+    D, N, S = 4, 4096, 60
+    prec = np.array([1.0, 4.0, (np.pi / 0.5) ** 2, 9.0])          # omega_2 * T = pi for T = 0.5
+    mu = np.array([1.0, -2.0, 3.0, 0.5])
+    pot = P.GaussianDiag(mu, prec=prec, const=0.0)
+
+    def run(jitter):
+        hmc = P.HMC(P.Ensemble(D, N), 0.5, 0.01, None, potential=pot, rng="philox", seed=4, verbose=False)
+        s_dev, _ = hmc.getSamples(S, 1 / kB, 0.05, device_output=True, jitter=jitter)
+        return hmc.sampleMoments(s_dev[:, :, 20:])
+    mean0, var0 = run(0.0)
+    mean1, var1 = run(0.3)
+    # without jitter the resonant coordinate never moves away from +-(q0 - mu): its spread over draws
+    # stays far from the posterior variance; with jitter mean and variance are recovered
+    assert abs(var0[2] * prec[2] - 1.0) > 0.5
+    assert np.max(np.abs(mean1 - mu)) < 0.02
+    assert np.max(np.abs(var1 * prec - 1.0)) < 0.06
