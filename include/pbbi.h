@@ -184,7 +184,8 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
  * kT = boltzmannConst*temperature).
  *   q_state (D,N; stride ldn): in = current positions, out = positions after S iterations
  *   samples_out (S, D, N) dense slabs <- samples_hmc   (device layout is S-major;
- *               the reference's (D,N,S) is a permuted view of it)
+ *               the reference's (D,N,S) is a permuted view of it); NULL = burn-in: the S
+ *               iterations only advance q_state (momenta_out must then be NULL too)
  *   momenta_out (S, D, N) or NULL;  reject_out (S, N) bytes or NULL;
  *   ratio_out (S, N) or NULL.
  */

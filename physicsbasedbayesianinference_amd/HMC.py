@@ -130,7 +130,7 @@ class HMC:
 
     # ------------------------------------------------------------------ sampling
     def getSamples(self, numSamples, temperature, qStd, rng=None, seed=None, device_output=False,
-                   chain0=0, iter0=0, host_stream=None, jitter=0.0):
+                   chain0=0, iter0=0, host_stream=None, jitter=0.0, burn_in=0):
         """HMC.getSamples (src/HMC.py:123-183): returns (samples_hmc, momentum_hmc), each
         (D, N, numSamples) with the sample index fastest.
 
@@ -143,7 +143,10 @@ class HMC:
         of leapfrog steps of every ITERATION uniformly from [L(1-jitter), L(1+jitter)] (one value
         for the whole ensemble, from a host stream seeded by `seed`, identical on every shard): a
         fixed trajectory length leaves modes with omega*T near k*pi unmixed; the mixture of
-        trajectory lengths is still a valid HMC kernel.
+        trajectory lengths is still a valid HMC kernel.  burn_in (rng="philox" only) runs that many
+        unrecorded iterations first (draw indices iter0 .. iter0+burn_in-1; the recorded ones
+        follow), without sample or momentum slabs: getSamples(S, burn_in=B) equals the last S
+        draws of getSamples(B + S).
         """
         pot = self._pot
         ens = self.ensemble
@@ -167,6 +170,8 @@ class HMC:
 
         if self.verbose:
             self.print_information()
+        if rng == "numpy" and (burn_in or jitter):
+            raise ValueError("burn_in / jitter need rng='philox' (the parity mode replays the reference's stream)")
         if rng == "numpy":
             # identical RNG consumption to the reference: q0, then per iteration p then u
             if host_stream is None:
@@ -195,6 +200,13 @@ class HMC:
             q_state = empty((D, N), dt, dev)
             _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D,
                       N, N, float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
+            if burn_in:
+                if jitter:
+                    raise ValueError("burn_in and jitter cannot be combined in one call")
+                _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                          mptr, None, None, None, None, N, N, h, L, int(burn_in), flags, seed,
+                          int(iter0), int(chain0), kT, stream)
+                iter0 = int(iter0) + int(burn_in)
             if jitter and S > 0:
                 if not 0.0 < jitter < 1.0:
                     raise ValueError("jitter must be in (0, 1)")
@@ -298,7 +310,7 @@ class HMC:
         stream = stream_ptr(dev)
         kT = float(boltzmannConst * temperature)
         q_state = empty((D, N), dt, dev)
-        sample, ratio = empty((1, D, N), dt, dev), empty((1, N), dt, dev)
+        ratio = empty((1, N), dt, dev)  # burn-in form of pbbi_hmc_run: no sample slab
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
         _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, int(chain0), D, N, N,
@@ -310,7 +322,7 @@ class HMC:
         for m in range(1, int(iterations) + 1):
             L = max(1, int(self.simulTime / h))
             _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
-                      sample.data_ptr(), None, None, ratio.data_ptr(), N, N, h, L, 1, run_flags, seed,
+                      None, None, None, ratio.data_ptr(), N, N, h, L, 1, run_flags, seed,
                       (1 << 40) + m, int(chain0), kT, stream)  # counters disjoint from getSamples'
             acc = torch.nan_to_num(torch.clamp(ratio[0].double(), max=1.0), nan=0.0).sum()
             cnt = torch.tensor(float(N), dtype=torch.float64, device=acc.device)

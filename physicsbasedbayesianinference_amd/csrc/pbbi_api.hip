@@ -457,47 +457,61 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
                  uint64_t iter0, uint64_t chain0, double kT, void* stream) {
     if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
     if (S < 0) return pbbi_fail(PBBI_ERR_INVALID, "S must be >= 0");
-    if ((!q_state || !samples_out) && N > 0 && S > 0)
-        return pbbi_fail(PBBI_ERR_INVALID, "q_state / samples_out must be non-NULL");
+    if (!q_state && N > 0 && S > 0) return pbbi_fail(PBBI_ERR_INVALID, "q_state must be non-NULL");
+    if (!samples_out && momenta_out)
+        return pbbi_fail(PBBI_ERR_INVALID, "momenta_out without samples_out (burn-in records nothing)");
     if (!(kT >= 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be >= 0");
     if (S == 0 || N == 0) return PBBI_OK;
     DeviceGuard guard(pot->device);
+    hipStream_t st = (hipStream_t)stream;
     const size_t es = elem_size(pot->dtype);
     const size_t slab = (size_t)pot->D * (size_t)N;  // elements per (D, N) sample slab
+    // samples_out == NULL: burn-in.  Nothing is recorded; the state ping-pongs between two scratch
+    // slabs (a third of the traffic of a recorded iteration is the momentum slab, which is skipped).
+    char* pong[2] = {nullptr, nullptr};
+    if (!samples_out) {
+        for (auto& p : pong)
+            if (hipMallocAsync((void**)&p, slab * es, st) != hipSuccess) {
+                if (pong[0]) (void)hipFreeAsync(pong[0], st);
+                return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the burn-in state");
+            }
+    }
+    auto slab_of = [&](int i) -> char* {
+        return samples_out ? (char*)samples_out + (size_t)i * slab * es : pong[i & 1];
+    };
     // paths that need device scratch (GEMM, workspace-streaming, user plugins) report what they
     // took in iteration 0; iterations 1.. carve the same from ONE arena instead of allocating again
     size_t need = 0;
     void* arena = nullptr;
-    for (int i = 0; i < S; ++i) {
+    int rc = PBBI_OK;
+    for (int i = 0; i < S && rc == PBBI_OK; ++i) {
         IterArgs a{};
         a.pot = pot; a.method = method; a.mass = mass;
-        // iteration i reads the state left by iteration i-1: the previous sample slab
-        a.q_in = (i == 0) ? q_state : (const char*)samples_out + (size_t)(i - 1) * slab * es;
+        // iteration i reads the state left by iteration i-1: the previous slab
+        a.q_in = (i == 0) ? (const char*)q_state : slab_of(i - 1);
         a.ldn_in = (i == 0) ? ldn : N;
-        a.q_out = (char*)samples_out + (size_t)i * slab * es;
+        a.q_out = slab_of(i);
         a.p_out = momenta_out ? (char*)momenta_out + (size_t)i * slab * es : nullptr;
         a.ldn_out = N;
         a.ratio_out = ratio_out ? (char*)ratio_out + (size_t)i * N * es : nullptr;
         a.reject_out = reject_out ? reject_out + (size_t)i * N : nullptr;
         a.N = N; a.h = h; a.L = L; a.flags = flags;
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
-        a.stream = (hipStream_t)stream;
+        a.stream = st;
         a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
-        if (int rc = route_hmc(a)) {
-            if (arena) (void)hipFreeAsync(arena, (hipStream_t)stream);
-            return rc;
-        }
-        if (i == 0 && need > 0 && S > 1 &&
-            hipMallocAsync(&arena, need, (hipStream_t)stream) != hipSuccess)
+        rc = route_hmc(a);
+        if (rc == PBBI_OK && i == 0 && need > 0 && S > 1 && hipMallocAsync(&arena, need, st) != hipSuccess)
             arena = nullptr;  // keep allocating per iteration
     }
-    if (arena) PBBI_HIP(hipFreeAsync(arena, (hipStream_t)stream));
+    if (arena) (void)hipFreeAsync(arena, st);
     // leave the chain state in q_state (strided D2D copy of the last slab)
-    PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * es,
-                              (const char*)samples_out + (size_t)(S - 1) * slab * es, (size_t)N * es,
-                              (size_t)N * es, (size_t)pot->D, hipMemcpyDeviceToDevice,
-                              (hipStream_t)stream));
-    return PBBI_OK;
+    if (rc == PBBI_OK &&
+        hipMemcpy2DAsync(q_state, (size_t)ldn * es, slab_of(S - 1), (size_t)N * es, (size_t)N * es,
+                         (size_t)pot->D, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        rc = pbbi_fail(PBBI_ERR_HIP, "hipMemcpy2DAsync of the final state failed");
+    for (char* p : pong)
+        if (p) (void)hipFreeAsync(p, st);
+    return rc;
 }
 
 // ============================================================================ RNG

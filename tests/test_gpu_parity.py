@@ -1342,3 +1342,37 @@ def test_trajectory_length_jitter_removes_resonance(P):
     assert abs(var0[2] * prec[2] - 1.0) > 0.5
     assert np.max(np.abs(mean1 - mu)) < 0.02
     assert np.max(np.abs(var1 * prec - 1.0)) < 0.06
+
+
+@pytest.mark.parametrize("kind", ["dense", "ros32", "diag64", "big200", "custom"])
+def test_burn_in_equals_discarding_draws(P, lib, kind):
+    """pbbi_hmc_run with samples_out = NULL (burn-in: the state ping-pongs between two scratch slabs,
+    nothing is recorded): getSamples(S, burn_in=B) is bit-identical to the last S draws of
+    getSamples(B + S), in every kernel family."""
+    from custom_sources import QUARTIC
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    rs = np.random.RandomState(2)
+    if kind in ("dense", "big200"):
+        D = 24 if kind == "dense" else 200
+        A = rs.standard_normal((D, D))
+        Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+        pot = P.GaussianDense(rs.standard_normal(D), precision=0.5 * (Pm + Pm.T), const=0.0)
+    elif kind == "ros32":
+        D, pot = 32, P.Rosenbrock(32)
+    elif kind == "diag64":
+        D, pot = 64, P.GaussianDiag(rs.standard_normal(64), prec=rs.uniform(0.5, 2, 64), const=0.0)
+    else:
+        D, pot = 12, CustomPotential(12, QUARTIC, [1.0, 0.5])
+    N, B, S = 257, 3, 4
+    h = 0.02 if kind == "ros32" else 0.1
+    kw = dict(potential=pot, rng="philox", seed=6, verbose=False)
+    full, _ = P.HMC(P.Ensemble(D, N), 10 * h + 1e-9, h, None, **kw).getSamples(B + S, 1 / kB, 0.5, chain0=5)
+    hmc = P.HMC(P.Ensemble(D, N), 10 * h + 1e-9, h, None, **kw)
+    part, _ = hmc.getSamples(S, 1 / kB, 0.5, chain0=5, burn_in=B)
+    assert np.array_equal(part, full[:, :, B:])
+    with pytest.raises(lib.PbbiError):   # a momentum slab without a sample slab
+        from physicsbasedbayesianinference_amd._device import empty, stream_ptr
+        q = empty((D, N), np.float64, 0)
+        m = empty((1, D, N), np.float64, 0)
+        lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, None, m.data_ptr(), None, None, N, N,
+                 h, 3, 1, 0, 1, 0, 0, 1.0, stream_ptr(0))

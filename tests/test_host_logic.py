@@ -213,6 +213,7 @@ def test_custom_potential_plugin_builds_and_exports():
     for src, dtype, D in ((QUARTIC, "float64", 11), (QUARTIC, "float64", 40), (LOGISTIC, "float64", 5),
                           (QUARTIC, "float32", 7), (COIN_TOSS_SOURCE, "float64", 1),
                           (QUARTIC, "float64", 9), (QUARTIC, "float64", 20), (QUARTIC, "float64", 24),
+                          (QUARTIC, "float64", 12),
                           (QUARTIC, "float64", None)):
         so = compile_plugin(src, dtype, D=D)
         syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
