@@ -116,11 +116,14 @@ def ensemble_weights(H_local, beta=1.0, group=None):
 
 def get_samples_sharded(potential, numDimensions, numParticles, simulTime, stepSize, numSamples,
                         temperature, qStd, method="Leapfrog", rng="philox", seed=0, mass=None,
-                        compat=True, group=None, gather=True, verbose=False):
+                        compat=True, group=None, gather=True, verbose=False, kdk_fma=None,
+                        jitter=0.0, burn_in=0):
     """HMC.getSamples over an ensemble of `numParticles` chains sharded across the process
     group (one rank per GPU).  Returns torch tensors (samples, momenta) shaped (D, N, S):
     the gathered ensemble when gather=True (one RCCL all-gather each), else this rank's
-    block.  `potential` must live on this rank's device."""
+    block.  `potential` must live on this rank's device.  kdk_fma / jitter / burn_in as in
+    HMC / HMC.getSamples (jitter's step counts come from a seed-derived host stream: the same on
+    every rank)."""
     from .ensemble import Ensemble
     from .HMC import HMC
     dist = _dist()
@@ -132,10 +135,10 @@ def get_samples_sharded(potential, numDimensions, numParticles, simulTime, stepS
     if mass is not None:
         ens.mass = np.asarray(mass, dtype=np.float64)[lo:hi].copy()
     hmc = HMC(ens, simulTime, stepSize, None, potential=potential, method=method, compat=compat,
-              rng=rng, seed=seed, verbose=verbose)
+              rng=rng, seed=seed, verbose=verbose, kdk_fma=kdk_fma)
     s, m = hmc.getSamples(numSamples, temperature, qStd, device_output=True, chain0=lo,
                           host_stream=HostStream(numDimensions, numParticles, lo, hi)
-                          if rng == "numpy" else None)
+                          if rng == "numpy" else None, jitter=jitter, burn_in=burn_in)
     s_sdn, m_sdn = s.permute(2, 0, 1), m.permute(2, 0, 1)  # back to the (S, D, N_local) slabs
     if gather and world > 1:
         s_sdn, m_sdn = gather_samples(s_sdn, group), gather_samples(m_sdn, group)
