@@ -188,6 +188,9 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
  *               iterations only advance q_state (momenta_out must then be NULL too)
  *   momenta_out (S, D, N) or NULL;  reject_out (S, N) bytes or NULL;
  *   ratio_out (S, N) or NULL.
+ * iter0 + S must not exceed 2^32: the Philox counter carries 32 iteration bits, a larger index
+ * would repeat the draws of iteration (index mod 2^32) and is refused (PBBI_ERR_INVALID).  Runs
+ * that must not share draws (a warm-up and the sampling that follows) use different seeds.
  */
 int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
                  void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,

@@ -37,6 +37,9 @@ from .integrator import Leapfrog, StormerVerlet, mass_or_none, resolve_potential
 
 __all__ = ["HMC"]
 
+# adaptStepSize's Philox key = seed ^ this (the sampling run keeps `seed`)
+WARMUP_SEED_MASK = 0xA5A55A5ADA7A0001
+
 
 class HMC:
     def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
@@ -306,6 +309,9 @@ class HMC:
         if N == 0:
             return float(self.stepSize)
         seed = self.seed if seed is None else int(seed)
+        # The warm-up draws from its own Philox KEY: the counter holds only 32 iteration bits
+        # (include/pbbi.h), so no iteration offset can keep its draws apart from getSamples'.
+        seed = (seed ^ WARMUP_SEED_MASK) & 0xFFFFFFFFFFFFFFFF
         dev, dt = pot.device, pot.dtype
         stream = stream_ptr(dev)
         kT = float(boltzmannConst * temperature)
@@ -323,7 +329,7 @@ class HMC:
             L = max(1, int(self.simulTime / h))
             _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
                       None, None, None, ratio.data_ptr(), N, N, h, L, 1, run_flags, seed,
-                      (1 << 40) + m, int(chain0), kT, stream)  # counters disjoint from getSamples'
+                      m, int(chain0), kT, stream)
             acc = torch.nan_to_num(torch.clamp(ratio[0].double(), max=1.0), nan=0.0).sum()
             cnt = torch.tensor(float(N), dtype=torch.float64, device=acc.device)
             if sharded:
@@ -338,7 +344,7 @@ class HMC:
             h = float(np.exp(log_h))
         h = float(np.exp(log_hbar))
         self.stepSize = self.integrator.stepSize = h
-        self.integrator.numSteps = int(self.simulTime / h)
+        self.integrator.numSteps = max(1, int(self.simulTime / h))  # what the warm-up itself ran
         return h
 
     def sampleMoments(self, samples_dns):

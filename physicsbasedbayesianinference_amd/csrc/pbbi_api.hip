@@ -461,6 +461,10 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
     if (!samples_out && momenta_out)
         return pbbi_fail(PBBI_ERR_INVALID, "momenta_out without samples_out (burn-in records nothing)");
     if (!(kT >= 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be >= 0");
+    // the Philox counter carries the low 32 bits of the iteration index (include/pbbi.h): a run that
+    // crosses 2^32 would silently repeat the draws of iterations 0, 1, ...
+    if (iter0 > UINT32_MAX || iter0 + (uint64_t)S > (uint64_t)UINT32_MAX + 1)
+        return pbbi_fail(PBBI_ERR_INVALID, "iter0 + S must be <= 2^32 (the Philox counter holds 32 iteration bits)");
     if (S == 0 || N == 0) return PBBI_OK;
     DeviceGuard guard(pot->device);
     hipStream_t st = (hipStream_t)stream;
@@ -519,6 +523,7 @@ int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t ch
                        int64_t N, int64_t ldn, double scale, const void* scale_per_chain,
                        int dtype, int device, void* out, void* stream) {
     if (D < 1 || N < 0 || ldn < N) return pbbi_fail(PBBI_ERR_INVALID, "bad D / N / ldn");
+    if (iter > UINT32_MAX) return pbbi_fail(PBBI_ERR_INVALID, "iter must be < 2^32");
     if (!out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
     if (N == 0) return PBBI_OK;
     DeviceGuard guard(device);
@@ -540,6 +545,7 @@ int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t ch
 int pbbi_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int dtype,
                         int device, void* out, void* stream) {
     if (N < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad N");
+    if (iter > UINT32_MAX) return pbbi_fail(PBBI_ERR_INVALID, "iter must be < 2^32");
     if (!out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
     if (N == 0) return PBBI_OK;
     DeviceGuard guard(device);

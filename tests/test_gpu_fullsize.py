@@ -1,0 +1,272 @@
+"""Full-size oracle spot checks of the entry points bench.py times (-m gpu), and a reject-branch
+stress of the dense MFMA kernel against the oracle.
+
+bench.py times `pbbi_hmc_run` (in-kernel Philox draws) at BASELINE's sizes:
+  C2  D=128 dense Gaussian,  N=65 536, fp64   -> k_dense_hmc (MODE 0, zero mean, FULL)
+  C3  Rosenbrock D=32,       N=262 144, fp64  -> k_ros2_hmc, PBBI_KDK_FMA and reference order
+  C5  D=4096 dense Gaussian, N=8 192,  fp32   -> k_big_gemm x (L+1)
+The oracle cannot run those sizes in seconds, but chains are independent (src/integrator.py:73,
+src/HMC.py:109-115,168-176): a few hundred chains spread over the first, last and random tiles
+of the FULL-SIZE launch are replayed in the oracle from the draws `pbbi_philox_normal` /
+`pbbi_philox_uniform` return for the same counters (include/pbbi.h: bit-identical to the in-kernel
+draws).  That checks the grid-dependent indexing of the timed kernels at the size they are timed
+at, which the small-N tests cannot.  Each case also runs with N - 5 chains (ragged last tile).
+
+Tolerances: reject masks equal; q, p scaled error <= 1e-11 (dense MFMA kernel: summation order),
+bit-exact (Rosenbrock, reference operation order), <= 1e-12 (PBBI_KDK_FMA), <= 2e-4 (C5: fp32
+kernel against the fp64 oracle; decisions compared where |log u - log ratio| > 1e-2).
+Reference behaviour matched: src/HMC.py:154-179.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_gpu_parity import device_normal, device_uniform, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+GROUP = 16  # chains per replayed group
+
+
+@pytest.fixture(scope="module")
+def P():
+    import physicsbasedbayesianinference_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from physicsbasedbayesianinference_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def chain_groups(N, n_groups, tile, seed):
+    """Starts of GROUP-chain runs: the first tile, the last chains of the ensemble, the two sides
+    of the last tile boundary, and random starts anywhere (they straddle tile boundaries)."""
+    rs = np.random.RandomState(seed)
+    starts = {0, N - GROUP, max(0, (N - 1) // tile * tile - GROUP // 2)}
+    while len(starts) < n_groups:
+        starts.add(int(rs.randint(0, N - GROUP)))
+    return sorted(starts)
+
+
+def device_normal_dtype(lib, seed, stream, it, chain0, D, N, scale, dtype):
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr, to_numpy
+    out = empty((D, N), dtype, 0)
+    lib.call("pbbi_philox_normal", seed, stream, it, chain0, D, N, N, float(scale), None,
+             lib.F64 if dtype == np.float64 else lib.F32, 0, out.data_ptr(), stream_ptr(0))
+    return to_numpy(out).astype(np.float64)
+
+
+def run_as_bench(lib, pot, D, N, S, h, L, flags, seed, q_scale, q_shift, dtype=np.float64, chain0=0):
+    """The calls of bench.py's main / main_c3 / main_c5: device-drawn q0, one pbbi_hmc_run over S
+    iterations with sample, momentum and reject slabs."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr
+    st = stream_ptr(0)
+    code = lib.F64 if dtype == np.float64 else lib.F32
+    q = empty((D, N), dtype, 0)
+    lib.call("pbbi_philox_normal", seed, lib.STREAM_POSITION, 0, chain0, D, N, N, float(q_scale), None,
+             code, 0, q.data_ptr(), st)
+    if q_shift:
+        q += q_shift
+    samples, momenta = empty((S, D, N), dtype, 0), empty((S, D, N), dtype, 0)
+    reject = empty((S, N), np.uint8, 0)
+    lib.call("pbbi_hmc_run", pot.handle, lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
+             momenta.data_ptr(), reject.data_ptr(), None, N, N, float(h), int(L), int(S), int(flags),
+             seed, 0, chain0, 1.0, st)
+    torch.cuda.synchronize()
+    return samples, momenta, reject, q
+
+
+def replay_groups(lib, op, starts, samples, momenta, reject, q_final, D, S, h, L, seed, q_scale,
+                  q_shift, compat, dtype, check):
+    """Oracle replay of the selected chains; `check(kind, gpu, ref, extra)` asserts per array."""
+    n_rej = n_tot = 0
+    for g in starts:
+        sl = slice(g, g + GROUP)
+        q = device_normal_dtype(lib, seed, lib.STREAM_POSITION, 0, g, D, GROUP, q_scale, dtype)
+        if q_shift:
+            q = (q.astype(dtype) + dtype(q_shift)).astype(np.float64)
+        q = np.ascontiguousarray(q)
+        for i in range(S):
+            p = np.ascontiguousarray(
+                device_normal_dtype(lib, seed, lib.STREAM_MOMENTUM, i, g, D, GROUP, 1.0, dtype))
+            u = device_uniform(lib, seed, i, g, GROUP)
+            ratio, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, None, h, L,
+                                      compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+            gq = samples[i, :, sl].cpu().numpy().astype(np.float64)
+            gp = momenta[i, :, sl].cpu().numpy().astype(np.float64)
+            grej = reject[i, sl].cpu().numpy().astype(bool)
+            check(g, i, gq, gp, grej, q, p, rej, ratio, u)
+            n_rej += int(rej.sum())
+            n_tot += GROUP
+            if dtype != np.float64:  # continue from the kernel's own state (fp32 drift is not the test)
+                q = np.ascontiguousarray(gq)
+        assert np.array_equal(q_final[:, sl].cpu().numpy().astype(np.float64),
+                              samples[S - 1, :, sl].cpu().numpy().astype(np.float64))
+    return n_rej, n_tot
+
+
+def c2_precision(D):
+    A = np.random.RandomState(0).standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    return 0.5 * (Pm + Pm.T)
+
+
+@pytest.mark.parametrize("ragged", [0, 5])
+def test_c2_full_size_hmc_run_vs_oracle(P, lib, ragged):
+    """bench.py's default workload: D=128, 65 536 chains, L=10, h=0.1, seed 42, compat flag."""
+    D, N, L, h, S, seed = 128, 65536 - ragged, 10, 0.1, 3, 42
+    Pm = c2_precision(D)
+    pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
+    samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, lib.COMPAT_P_FROM_OLDQ, seed,
+                                                1.0, 0.0)
+    worst = [0.0]
+
+    def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
+        assert np.array_equal(grej, rej), f"group {g} iteration {i}"
+        worst[0] = max(worst[0], scaled_err(gq, q), scaled_err(gp, p))
+    n_rej, n_tot = replay_groups(lib, op, chain_groups(N, 16, 128, 1), samples, momenta, reject, qf, D, S,
+                                 h, L, seed, 1.0, 0.0, True, np.float64, check)
+    assert worst[0] <= 1e-11, worst[0]
+    assert n_tot == 16 * GROUP * S
+    # the whole ensemble's accept rate is what bench.py reports as config.accept_rate
+    assert 0.5 < 1.0 - float(reject.float().mean()) <= 1.0
+
+
+@pytest.mark.parametrize("kdk,ragged", [(True, 0), (False, 0), (True, 5), (False, 5)])
+def test_c3_full_size_hmc_run_vs_oracle(P, lib, kdk, ragged):
+    """bench.py --workload c3 [--exact-order]: Rosenbrock D=32, 262 144 chains, h=0.01, L=10,
+    q0 = 1 + 0.1 z, seed 7."""
+    D, N, L, h, S, seed = 32, 262144 - ragged, 10, 0.01, 3, 7
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    flags = lib.COMPAT_P_FROM_OLDQ | (lib.KDK_FMA if kdk else 0)
+    samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, flags, seed, 0.1, 1.0)
+    worst = [0.0]
+
+    def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
+        assert np.array_equal(grej, rej), f"group {g} iteration {i}"
+        if kdk:
+            worst[0] = max(worst[0], scaled_err(gq, q), scaled_err(gp, p))
+        else:
+            assert np.array_equal(gq, q) and np.array_equal(gp, p), f"group {g} iteration {i}"
+    replay_groups(lib, op, chain_groups(N, 16, 32, 2), samples, momenta, reject, qf, D, S, h, L, seed,
+                  0.1, 1.0, True, np.float64, check)
+    assert worst[0] <= 1e-12, worst[0]
+
+
+@pytest.mark.parametrize("ragged", [0, 5])
+def test_c5_full_size_hmc_run_vs_oracle(P, lib, ragged):
+    """bench.py --workload c5: D=4096 dense precision, 8 192 chains, fp32, h=0.05, L=10, seed 7.
+    fp32 kernel against the fp64 oracle restarted from the kernel's own previous state."""
+    D, N, L, h, S, seed = 4096, 8192 - ragged, 10, 0.05, 2, 7
+    Pm = c2_precision(D)
+    pot = P.GaussianDense(None, precision=Pm, const=0.0, dtype="float32")
+    op = orc.pot_gauss_dense(np.zeros(D), Pm)
+    samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, lib.COMPAT_P_FROM_OLDQ, seed,
+                                                1.0, 0.0, dtype=np.float32)
+    worst, clear_n = [0.0], [0]
+
+    def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
+        with np.errstate(divide="ignore"):
+            clear = np.abs(np.log(u) - np.minimum(0.0, np.log(ratio))) > 1e-2
+        assert np.array_equal(grej[clear], rej[clear]), f"group {g} iteration {i}"
+        same = grej == rej  # compare states where the decision agrees (all of `clear`)
+        worst[0] = max(worst[0], scaled_err(gq[:, same], q[:, same]), scaled_err(gp[:, same], p[:, same]))
+        clear_n[0] += int(clear.sum())
+    starts = [0, N - GROUP, 120, 4090]  # first column tile, last (ragged) one, two tile boundaries
+    replay_groups(lib, op, starts, samples, momenta, reject, qf, D, S, h, L, seed, 1.0, 0.0, True,
+                  np.float32, check)
+    assert worst[0] <= 2e-4, worst[0]
+    assert clear_n[0] > len(starts) * GROUP * S // 2
+
+
+# ---------------------------------------------------------------------------------------------
+# Reject-branch stress of k_dense_hmc (kernels_dense.hip, the branch after `if (reject)`): the old
+# position is re-loaded (src/HMC.py:175) and the stored momentum is one of
+#   compat:              the OLD POSITION          (src/HMC.py:176)
+#   non-compat, Philox:  the draw parked in the momentum slab before the trajectory
+#   non-compat, upload:  p_in re-loaded
+# h = 0.5, L = 4 rejects 40-60 % of the chains; the uploaded mode also forces u[::3] = 1.5.
+# ---------------------------------------------------------------------------------------------
+def _stress_problem(D, zero_mean):
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    mu = np.zeros(D) if zero_mean else rs.standard_normal(D)
+    return Pm, mu
+
+
+@pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
+@pytest.mark.parametrize("compat", [True, False])
+@pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
+                                              (100, False, False), (64, False, False), (24, True, True)])
+def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, method):
+    from test_gpu_parity import gpu_hmc_iter
+    N, h, L = 333, 0.5, 4  # ragged: 333 = 2*128 + 77
+    Pm, mu = _stress_problem(D, zero_mean)
+    pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
+    op = orc.pot_gauss_dense(mu, Pm, 0.25)
+    rs = np.random.RandomState(7 * D + N)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    q = rs.standard_normal((D, N)) + mu[:, None]
+    n_rej = 0
+    for it in range(2):
+        p = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+        u = rs.uniform(size=N)
+        u[::3] = 1.5  # forced rejections (u > min(1, ratio) always)
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, m, h, L, compat=compat)
+        q_or, p_or = q.copy(), p.copy()
+        r_or, rej_or = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L,
+                                    compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(rej, rej_or) and rej[::3].all()
+        assert scaled_err(qo, q_or) <= 1e-11 and scaled_err(po, p_or) <= 1e-11
+        # rejected chains hold exact copies, not recomputed values
+        assert np.array_equal(qo[:, rej], q[:, rej])
+        assert np.array_equal(po[:, rej], q[:, rej] if compat else p[:, rej])
+        n_rej += int(rej.sum())
+        q = qo
+    assert n_rej >= 0.3 * 2 * N
+
+
+@pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
+@pytest.mark.parametrize("compat", [True, False])
+@pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
+                                              (100, False, False)])
+def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat, method):
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    N, h, L, S, seed, chain0, iter0 = 333, 0.5, 4, 3, 11, 77, 5
+    Pm, mu = _stress_problem(D, zero_mean)
+    pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
+    op = orc.pot_gauss_dense(mu, Pm, 0.25)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    st = stream_ptr(0)
+    q0 = device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 1.0) + mu[:, None]
+    qd = as_device(q0, 0, np.float64)
+    samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+    reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
+    lib.call("pbbi_hmc_run", pot.handle, orc.METHODS[method], qd.data_ptr(),
+             md.data_ptr() if mass else None, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
+             ratio.data_ptr(), N, N, h, L, S, lib.COMPAT_P_FROM_OLDQ if compat else 0, seed, iter0, chain0,
+             1.0, st)
+    torch.cuda.synchronize()
+    samples, momenta, reject = to_numpy(samples), to_numpy(momenta), to_numpy(reject).astype(bool)
+    q = np.ascontiguousarray(q0)
+    pstd = np.sqrt(m) if mass else np.ones(N)
+    n_rej = 0
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, iter0 + i, chain0, D, N, 1.0, pstd)
+        u = device_uniform(lib, seed, iter0 + i, chain0, N)
+        q_old, p_draw = q.copy(), p.copy()
+        _, rej = orc.hmc_iter(op, method, q, p, u, m, h, L, compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
+        assert np.array_equal(reject[i], rej), f"iteration {i}"
+        assert scaled_err(samples[i], q) <= 1e-11 and scaled_err(momenta[i], p) <= 1e-11
+        assert np.array_equal(momenta[i][:, rej], q_old[:, rej] if compat else p_draw[:, rej])
+        n_rej += int(rej.sum())
+    assert n_rej >= 0.3 * S * N
+    assert np.array_equal(to_numpy(qd), samples[S - 1])

@@ -965,11 +965,36 @@ def test_dual_averaging_step_size(P):
     for h0 in (0.01, 1.5):
         hmc = P.HMC(P.Ensemble(D, N), 1.0, h0, None, potential=pot, rng="philox", seed=5, verbose=False)
         h = hmc.adaptStepSize(1.0 / kB, 1.0, target=0.8, iterations=150)
-        assert hmc.stepSize == h and hmc.integrator.numSteps == int(1.0 / h)
+        assert hmc.stepSize == h and hmc.integrator.numSteps == max(1, int(1.0 / h))
         hmc.getSamples(20, 1.0 / kB, 1.0)
         assert abs(np.minimum(1.0, hmc.ratios[5:]).mean() - 0.8) < 0.1, (h0, h)
         steps.append(h)
     assert abs(steps[0] / steps[1] - 1.0) < 0.35
+
+
+def test_warmup_draws_are_disjoint_from_sampling_draws(P, lib):
+    """adaptStepSize draws under its own Philox key (seed ^ WARMUP_SEED_MASK): the counter holds only
+    32 iteration bits, so an iteration offset such as 1 << 40 would alias the sampling run's draws
+    (iteration_lo32, include/pbbi.h).  pbbi_hmc_run / pbbi_philox_* refuse indices beyond 2^32."""
+    from physicsbasedbayesianinference_amd.HMC import WARMUP_SEED_MASK
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr
+    seed, D, N = 5, 8, 64
+    z = device_normal(lib, seed, lib.STREAM_MOMENTUM, 3, 0, D, N)
+    zw = device_normal(lib, seed ^ WARMUP_SEED_MASK, lib.STREAM_MOMENTUM, 3, 0, D, N)
+    assert not np.any(z == zw)
+    assert not np.any(device_uniform(lib, seed, 3, 0, N) == device_uniform(lib, seed ^ WARMUP_SEED_MASK, 3, 0, N))
+    # what the old offset did: iteration (1 << 32) + 3 would be iteration 3 again -> now an error
+    q = empty((D, N), np.float64, 0)
+    pot = P.StandardGaussian(D)
+    for it0, S in (((1 << 32) + 3, 1), ((1 << 32) - 1, 2), (1 << 40, 1)):
+        with pytest.raises(lib.PbbiError):
+            lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, None, None, None, None, N, N, 0.1, 3,
+                     S, 0, seed, it0, 0, 1.0, stream_ptr(0))
+    with pytest.raises(lib.PbbiError):
+        lib.call("pbbi_philox_normal", seed, lib.STREAM_MOMENTUM, 1 << 32, 0, D, N, N, 1.0, None, lib.F64, 0,
+                 q.data_ptr(), stream_ptr(0))
+    lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, None, None, None, None, N, N, 0.1, 3,
+             1, 0, seed, (1 << 32) - 1, 0, 1.0, stream_ptr(0))  # the last valid index
 
 
 @pytest.mark.parametrize("D,N,mass,compat", [(32, 2500, False, True), (32, 333, True, False),
@@ -1376,3 +1401,61 @@ def test_burn_in_equals_discarding_draws(P, lib, kind):
         m = empty((1, D, N), np.float64, 0)
         lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, None, m.data_ptr(), None, None, N, N,
                  h, 3, 1, 0, 1, 0, 0, 1.0, stream_ptr(0))
+
+
+# ------------------------------------------------------------------ SURVEY 8a rows a5 / a9
+@pytest.mark.parametrize("kind", ["harmonic", "dense", "rosenbrock"])
+def test_integrator_getaccel_with_masses(P, kind):
+    """Integrator.getAccel(i) = -gradient(q[:, i]) / mass[i]  (src/integrator.py:61-73): sign and
+    the division by the chain's own mass, against the oracle's gradient."""
+    rs = np.random.RandomState(3)
+    if kind == "harmonic":
+        D, k = 3, np.array([2.0, 3.0, 0.5])
+        pot, op = P.Harmonic(k), orc.pot_harmonic(k)
+    elif kind == "dense":
+        D = 8
+        A = rs.standard_normal((D, D))
+        Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+        Pm, mu = 0.5 * (Pm + Pm.T), rs.standard_normal(D)
+        pot, op = P.GaussianDense(mu, precision=Pm, const=0.0), orc.pot_gauss_dense(mu, Pm)
+    else:
+        D = 5
+        pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    N = 7
+    ens = P.Ensemble(D, N)
+    ens.q = rs.standard_normal((D, N))
+    ens.mass = 1.0 + 0.75 * np.arange(N)           # all different, none equal to 1 except chain 0
+    integ = P.Leapfrog(ens, 0.1, 1.0, pot.gradient)
+    _, g = orc.potential(op, ens.q, want_grad=True)
+    for i in range(N):
+        a = integ.getAccel(i)
+        assert a.shape == (D,)
+        ref = -g[:, i] / ens.mass[i]
+        if kind == "dense":
+            assert scaled_err(a, ref) <= RTOL_DENSE
+        else:
+            assert np.array_equal(a, ref)
+    # one chain, checked by hand: harmonic a = -k*q/m
+    if kind == "harmonic":
+        assert np.allclose(integ.getAccel(2), -k * ens.q[:, 2] / 2.5, rtol=0, atol=1e-15)
+
+
+def test_hmc_from_density_only(P):
+    """HMC(ens, T, h, density) with potential=None (src/HMC.py:52-56): the potential is
+    potentialFunc = -log(density) (src/HMC.py:75-84) and sampling reproduces config C1 (G3)."""
+    g = load_golden("G3_getsamples_c1")
+    D, N, S = int(g["D"]), int(g["N"]), int(g["S"])
+    pot = P.StandardGaussian(D)
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, float(g["simulTime"]), float(g["stepSize"]), pot.density, verbose=False)
+    assert hmc.potential == hmc.potentialFunc and hmc.density == pot.density
+    q = np.array([[0.3, -1.2, 2.0]])
+    U = hmc.potentialFunc(q)                                    # -log(exp(-U)) on the HIP eval kernel
+    assert U.shape == (3,)
+    assert np.max(np.abs(U - orc.potential(orc.pot_gauss_diag(np.zeros(D), np.ones(D)), q))) < 1e-14
+    assert abs(hmc.potentialFunc(np.array([0.5])) - 0.125) < 1e-15
+    samples, momenta = hmc.getSamples(S, float(g["temperature"]), float(g["qStd"]))
+    assert np.array_equal(hmc.reject_masks, g["reject_mask"])
+    assert scaled_err(samples, g["samples"]) <= RTOL_GOLDEN
+    assert scaled_err(momenta, g["momenta"]) <= RTOL_GOLDEN
