@@ -262,11 +262,14 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
     for i in range(S):
         p = device_normal(lib, seed, lib.STREAM_MOMENTUM, iter0 + i, chain0, D, N, 1.0, pstd)
         u = device_uniform(lib, seed, iter0 + i, chain0, N)
-        q_old, p_draw = q.copy(), p.copy()
+        p_draw = p.copy()
         _, rej = orc.hmc_iter(op, method, q, p, u, m, h, L, compat=orc.COMPAT_P_FROM_OLDQ if compat else 0)
         assert np.array_equal(reject[i], rej), f"iteration {i}"
         assert scaled_err(samples[i], q) <= 1e-11 and scaled_err(momenta[i], p) <= 1e-11
-        assert np.array_equal(momenta[i][:, rej], q_old[:, rej] if compat else p_draw[:, rej])
+        # rejected chains hold exact copies: of the kernel's own previous position, or of the draw
+        gpu_old = q0 if i == 0 else samples[i - 1]
+        assert np.array_equal(samples[i][:, rej], gpu_old[:, rej])
+        assert np.array_equal(momenta[i][:, rej], gpu_old[:, rej] if compat else p_draw[:, rej])
         n_rej += int(rej.sum())
     assert n_rej >= 0.3 * S * N
     assert np.array_equal(to_numpy(qd), samples[S - 1])
