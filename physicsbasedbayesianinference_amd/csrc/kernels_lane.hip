@@ -567,6 +567,14 @@ int lane_hmc_iter(const IterArgs& a) {
     if (!no_lane2 && lane2_applies(a)) return lane2_hmc_iter(a);
     return launch_hmc<double>(a);
 }
+int lane_fused_iterations(const IterArgs& a) {
+    // only the two-lane Rosenbrock kernel keeps a chain in registers across iterations so far
+    static const int fuse = getenv("PBBI_FUSE_ITERS") ? atoi(getenv("PBBI_FUSE_ITERS")) : 16;
+    static const bool no_lane2 = (getenv("PBBI_NO_LANE2") != nullptr);
+    if (fuse <= 1 || no_lane2 || !a.rng || a.N == 0 || !lane2_applies(a) || streams(a.pot)) return 1;
+    if (check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) != PBBI_OK) return 1;
+    return fuse;
+}
 int lane_integrate(const IntegrateArgs& a) {
     if (streams(a.pot)) return stream_integrate(a);
     if (int rc = check_ld(a.pot, a.ldn)) return rc;

@@ -15,6 +15,8 @@
 // Arithmetic and summation ORDER are exactly the oracle's (and the chain-per-lane kernel's):
 // the sequential energy sums are continued across the halves (half 1 starts from half 0's
 // prefix), so q, p are bit-exact against the oracle, as for every chain-per-lane kernel.
+#include <cstdlib>
+
 #include "pbbi_buf.h"
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
@@ -26,6 +28,9 @@ constexpr int CHAINS_PER_BLOCK = 32; // C3 balance the last dispatch round bette
 constexpr int DL = 16;               // dims per lane
 
 struct Ros2Prm {
+#ifdef PBBI_STAMPS_ROS2
+    unsigned long long* stamps;
+#endif
     const double* q_in;
     const double* p_in;
     const double* u_in;
@@ -41,6 +46,37 @@ struct Ros2Prm {
 };
 
 __device__ __forceinline__ double xchg(double x) { return __shfl_xor(x, 32, 64); }
+
+#ifdef PBBI_STAMPS_ROS2
+// Diagnostic build only (tools/build_stamps_ros2.sh, tools/ros2_timeline.py): per-tile
+// s_memrealtime stamps (100 MHz, one clock for the chip) and the hardware wave slot, written to a
+// buffer of their own.  Read the TIMELINE of such a build, never its run time.
+static unsigned long long* g_ros2_stamps = nullptr;
+extern "C" void pbbi_debug_set_ros2_stamp_buffer(void* p) { g_ros2_stamps = (unsigned long long*)p; }
+#define RSTAMP(tile, i)                                                                        \
+    do {                                                                                       \
+        if (prm.stamps && (threadIdx.x & 63) == 0) {                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            prm.stamps[(size_t)(tile) * 8 + (i)] = t_;                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+#define RSTAMP_HWID(tile)                                                                      \
+    do {                                                                                       \
+        if (prm.stamps && (threadIdx.x & 63) == 0) {                                           \
+            unsigned hw_, xcc_;                                                                \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                  \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                \
+            prm.stamps[(size_t)(tile) * 8 + 7] = hw_;                                          \
+            prm.stamps[(size_t)(tile) * 8 + 6] = xcc_;                                         \
+        }                                                                                      \
+    } while (0)
+#else
+#define RSTAMP(tile, i) do { } while (0)
+#define RSTAMP_HWID(tile) do { } while (0)
+#endif
 
 // FULL: D == 32.  Then every dim exists and only the chain's last dim (half 1, j = 15) lacks a
 // right neighbour, so the per-lane predicates below fold to compile-time constants except for
@@ -174,18 +210,13 @@ __device__ __forceinline__ double pp_pair(const double (&p)[DL]) {
     return s + xchg(s);
 }
 
+// One HMC iteration of the wave's 32 chains once their positions are in q[]: momentum (drawn or
+// uploaded), H_old, the trajectory, H_new, the decision and the stores (src/HMC.py:154-179).
+// n0 = first chain of the tile (wave-uniform), c = chain within the tile, half = which 16 dims.
 template <bool UNIT, bool FULL, bool KDK>
-__global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, c = lane & 31;
-    const int64_t n0 = (int64_t)blockIdx.x * CHAINS_PER_BLOCK;  // block-uniform
-    const int cb = wave * 32 + c;                               // chain within the block
-    if (n0 + cb - c >= prm.N) return;                           // whole wave out of range
-    const int64_t left = prm.N - n0;
-    const bool valid = cb < left;
-    const int cc = valid ? cb : (int)left - 1;
+__device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& pot, int64_t n0, int c,
+                                          int half, bool valid, int cc, double (&q)[DL]) {
     const int D = prm.D;
-    const Ros2<FULL> pot{prm.a, prm.b, prm.inv_s, prm.cst, prm.c1, prm.c2, prm.c3, D, half};
     const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
     const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
     // buffer addressing: per-lane byte offset = column + this half's first row; row j via soffset
@@ -200,9 +231,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
     const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return pot.exists(j); };
 
-    double q[DL], v[DL], a[DL];  // v holds p, then the velocity, then p again
-#pragma unroll
-    for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
+    double v[DL], a[DL];  // v holds p, then the velocity, then p again
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
     auto draw = [&]() {
 #pragma unroll
@@ -229,6 +258,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
         if (!half) oldH = o;
     }
 
+    RSTAMP(n0 / CHAINS_PER_BLOCK, 2);
     // ---- Leapfrog.integrate, src/integrator.py:105-120 (operation order kept)
     // hh2, hh: bit-identical cheaper forms of (0.5*a)*h**2 and (0.5*(a+a'))*h (kernels_lane.hip)
     const double h = prm.h, hh2 = 0.5 * (prm.h * prm.h), hh = 0.5 * prm.h;
@@ -272,6 +302,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
         const double o = xchg(newH);
         if (!half) newH = o;
     }
+    RSTAMP(n0 / CHAINS_PER_BLOCK, 3);
     const double ratio = exp(oldH - newH);  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
@@ -300,10 +331,81 @@ __global__ void __launch_bounds__(BLOCK, 3) k_ros2_hmc(Ros2Prm prm) {
                 buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
         }
         if (half == 0) {
-            if (prm.ratio_out) prm.ratio_out[n0 + cb] = ratio;
-            if (prm.reject_out) prm.reject_out[n0 + cb] = reject ? 1 : 0;
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
         }
     }
+    RSTAMP(n0 / CHAINS_PER_BLOCK, 4);
+}
+
+// waves per SIMD: the kick-drift-kick form (64 state registers) runs four (three with per-chain
+// masses), the reference-order form (96) two, all without scratch (tools/kernel_resources.py)
+#ifndef PBBI_ROS2_WAVES_KDK
+#define PBBI_ROS2_WAVES_KDK 4
+#endif
+#ifndef PBBI_ROS2_WAVES_EXACT
+#define PBBI_ROS2_WAVES_EXACT 2
+#endif
+
+// Where the iterations of a fused run put their results (pbbi_hmc_run, IterArgs::fuse_*): iteration k
+// of the launch writes position slab (slab0 + k), modulo 2 for a burn-in's two scratch slabs, and
+// momentum slab k; ratio / reject rows k.
+struct Ros2Run {
+    int S;            // iterations in this launch (1: plain pbbi_hmc_iter semantics)
+    int wrap2;        // position slabs alternate between slab 0 and 1 of q_base (burn-in)
+    int64_t slab0;    // index of the first iteration's position slab
+    int64_t slab;     // elements per slab (D * N)
+    double* q_base;   // slab 0 of the position slabs
+};
+
+// One 32-chain tile per one-wave workgroup; the chain stays in registers for run.S consecutive HMC
+// iterations (config C3's launch: the same 262 144 chains, iteration after iteration).  An iteration
+// launched on its own spends a quarter of its time outside the vector pipes' steady state
+// (tools/ros2_timeline.py: 4 us until the first trajectory starts because every wave of the first
+// round loads and draws at once, 8 us of emptying chip at the end, slot turnover in between); fused,
+// a wave pays the load once per launch, only samples leave the chip, and waves that share a SIMD
+// drift out of step within a few iterations, so that one wave's draw (32-bit multiplies, xors) and
+// stores run beside another's trajectory (fp64).
+template <bool UNIT, bool FULL, bool KDK>
+__global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBBI_ROS2_WAVES_KDK - 1)
+                                              : PBBI_ROS2_WAVES_EXACT)
+    k_ros2_hmc(Ros2Prm prm, Ros2Run run) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, c = lane & 31;
+    const int64_t n0 = (int64_t)blockIdx.x * CHAINS_PER_BLOCK;  // block-uniform
+    if (n0 >= prm.N) return;
+    RSTAMP(blockIdx.x, 0);
+    RSTAMP_HWID(blockIdx.x);
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;
+    const Ros2<FULL> pot{prm.a, prm.b, prm.inv_s, prm.cst, prm.c1, prm.c2, prm.c3, prm.D, half};
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in;
+    const uint32_t vin = 8u * (uint32_t)cc + (uint32_t)(16 * half) * rin;
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0, prm.D, prm.ldn_in, prm.N, n0, 8);
+    double q[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
+#pragma nounroll
+    for (int k = 0; k < run.S; ++k) {
+        Ros2Prm it = prm;  // this iteration's view: where a rejected chain re-reads its position, where the results go
+        const int64_t s_out = run.wrap2 ? ((run.slab0 + k) & 1) : run.slab0 + k;
+        const int64_t s_prev = run.wrap2 ? ((run.slab0 + k - 1) & 1) : run.slab0 + k - 1;
+        if (k > 0) {
+            it.q_in = run.q_base + s_prev * run.slab;
+            it.ldn_in = prm.ldn_out;
+        }
+        it.q_out = run.q_base + s_out * run.slab;
+        if (prm.p_out) it.p_out = prm.p_out + (int64_t)k * run.slab;
+        if (prm.ratio_out) it.ratio_out = prm.ratio_out + (int64_t)k * prm.N;
+        if (prm.reject_out) it.reject_out = prm.reject_out + (int64_t)k * prm.N;
+        it.iter = prm.iter + (uint64_t)k;
+        ros2_tile<UNIT, FULL, KDK>(it, pot, n0, c, half, valid, cc, q);
+    }
+#ifdef PBBI_STAMPS_ROS2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSTAMP(blockIdx.x, 5);
+#endif
 }
 
 }  // namespace
@@ -318,19 +420,26 @@ bool lane2_applies(const IterArgs& a) {
 int lane2_hmc_iter(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (a.N == 0) return PBBI_OK;
-    Ros2Prm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+    Ros2Prm prm{
+#ifdef PBBI_STAMPS_ROS2
+                g_ros2_stamps,
+#endif
+                (const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
                 (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
                 a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, 1.0 / pot->s, pot->cst,
                 a.kT, (-4.0 * pot->b) * (1.0 / pot->s), 2.0 * (1.0 / pot->s),
                 (2.0 * pot->b) * (1.0 / pot->s), a.L, pot->D, a.flags, a.rng, a.seed, a.iter,
                 a.chain0};
+    // a single iteration is a run of one whose only "slab" is q_out
+    Ros2Run run{1, 0, 0, (int64_t)pot->D * a.N, (double*)a.q_out};
+    if (a.fuse_S > 1) run = Ros2Run{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)pot->D * a.N, (double*)a.fuse_q_base};
     const dim3 grid((unsigned)((a.N + CHAINS_PER_BLOCK - 1) / CHAINS_PER_BLOCK)), block(BLOCK);
     const bool full = (pot->D == 32);
     const bool kdk = (a.flags & PBBI_KDK_FMA) != 0;
-#define ROS2_LAUNCH(U_, F_)                                                                     \
-    {                                                                                           \
-        if (kdk) hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true>), grid, block, 0, a.stream, prm); \
-        else hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false>), grid, block, 0, a.stream, prm);    \
+#define ROS2_LAUNCH(U_, F_)                                                                          \
+    {                                                                                                \
+        if (kdk) hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true>), grid, block, 0, a.stream, prm, run); \
+        else hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false>), grid, block, 0, a.stream, prm, run);    \
     }
     if (a.mass) {
         if (full) ROS2_LAUNCH(false, true) else ROS2_LAUNCH(false, false)

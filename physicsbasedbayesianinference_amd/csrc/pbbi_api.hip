@@ -20,6 +20,16 @@ int pbbi_fail(int code, const std::string& msg) {
     return code;
 }
 
+int pbbi_num_cus(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+        cus = 256;
+    if (device >= 0 && device < 64) cached[device] = cus;
+    return cus;
+}
+
 namespace {
 
 inline size_t elem_size(int dtype) { return dtype == PBBI_F64 ? 8 : 4; }
@@ -126,6 +136,12 @@ int route_hmc(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
     return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
+}
+// consecutive iterations of pbbi_hmc_run that ONE route_hmc call may cover (IterArgs::fuse_*)
+int route_fused_iterations(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->kind == KIND_CUSTOM || is_big(pot) || is_dense(pot)) return 1;
+    return lane_fused_iterations(a);
 }
 int route_integrate(const IntegrateArgs& a) {
     const pbbi_potential* pot = a.pot;
@@ -472,23 +488,18 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
     const size_t slab = (size_t)pot->D * (size_t)N;  // elements per (D, N) sample slab
     // samples_out == NULL: burn-in.  Nothing is recorded; the state ping-pongs between two scratch
     // slabs (a third of the traffic of a recorded iteration is the momentum slab, which is skipped).
-    char* pong[2] = {nullptr, nullptr};
-    if (!samples_out) {
-        for (auto& p : pong)
-            if (hipMallocAsync((void**)&p, slab * es, st) != hipSuccess) {
-                if (pong[0]) (void)hipFreeAsync(pong[0], st);
-                return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the burn-in state");
-            }
-    }
+    char* pong = nullptr;
+    if (!samples_out && hipMallocAsync((void**)&pong, 2 * slab * es, st) != hipSuccess)
+        return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the burn-in state");
     auto slab_of = [&](int i) -> char* {
-        return samples_out ? (char*)samples_out + (size_t)i * slab * es : pong[i & 1];
+        return samples_out ? (char*)samples_out + (size_t)i * slab * es : pong + (size_t)(i & 1) * slab * es;
     };
     // paths that need device scratch (GEMM, workspace-streaming, user plugins) report what they
     // took in iteration 0; iterations 1.. carve the same from ONE arena instead of allocating again
     size_t need = 0;
     void* arena = nullptr;
     int rc = PBBI_OK;
-    for (int i = 0; i < S && rc == PBBI_OK; ++i) {
+    for (int i = 0; i < S && rc == PBBI_OK;) {
         IterArgs a{};
         a.pot = pot; a.method = method; a.mass = mass;
         // iteration i reads the state left by iteration i-1: the previous slab
@@ -503,9 +514,19 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = st;
         a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
+        // kernels that keep the chain on chip take several iterations per launch
+        int chunk = route_fused_iterations(a);
+        if (chunk > S - i) chunk = S - i;
+        if (chunk > 1) {
+            a.fuse_S = chunk;
+            a.fuse_wrap2 = samples_out ? 0 : 1;
+            a.fuse_slab0 = i;
+            a.fuse_q_base = samples_out ? samples_out : (void*)pong;
+        }
         rc = route_hmc(a);
         if (rc == PBBI_OK && i == 0 && need > 0 && S > 1 && hipMallocAsync(&arena, need, st) != hipSuccess)
             arena = nullptr;  // keep allocating per iteration
+        i += chunk > 1 ? chunk : 1;
     }
     if (arena) (void)hipFreeAsync(arena, st);
     // leave the chain state in q_state (strided D2D copy of the last slab)
@@ -513,8 +534,7 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         hipMemcpy2DAsync(q_state, (size_t)ldn * es, slab_of(S - 1), (size_t)N * es, (size_t)N * es,
                          (size_t)pot->D, hipMemcpyDeviceToDevice, st) != hipSuccess)
         rc = pbbi_fail(PBBI_ERR_HIP, "hipMemcpy2DAsync of the final state failed");
-    for (char* p : pong)
-        if (p) (void)hipFreeAsync(p, st);
+    if (pong) (void)hipFreeAsync(pong, st);
     return rc;
 }
 

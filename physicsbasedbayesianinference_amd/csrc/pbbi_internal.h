@@ -10,7 +10,7 @@
 enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3, KIND_CUSTOM = 4 };
 
 // layout version of the structs a user-potential plugin (pbbi_custom.h) shares with libpbbi.so
-#define PBBI_PLUGIN_ABI 2
+#define PBBI_PLUGIN_ABI 3
 
 struct IterArgs;
 struct IntegrateArgs;
@@ -65,6 +65,7 @@ struct DeviceGuard {  // make the handle's device current for the duration of a 
     }
 };
 
+int pbbi_num_cus(int device);  // compute units of a device (cached), pbbi_api.hip
 // ---- launch descriptors passed between api and kernel TUs ---------------------
 struct IterArgs {
     const pbbi_potential* pot;
@@ -92,6 +93,15 @@ struct IterArgs {
     void* scratch;
     size_t scratch_bytes;
     size_t* scratch_used;
+    // Fused run (pbbi_hmc_run on a path that keeps the chain on chip across iterations, see
+    // pbbi_fused_iterations): fuse_S > 1 makes this ONE call cover draw indices iter .. iter+fuse_S-1.
+    // Iteration k of the call writes position slab fuse_slab0 + k of fuse_q_base (D*N elements each,
+    // stride N; modulo 2 when fuse_wrap2: a burn-in's two scratch slabs), p_out + k*D*N,
+    // ratio_out + k*N, reject_out + k*N; q_in / ldn_in feed iteration 0 only.
+    int fuse_S;
+    int fuse_wrap2;
+    int64_t fuse_slab0;
+    void* fuse_q_base;
 };
 
 struct IntegrateArgs {
@@ -158,6 +168,9 @@ int lane_energy(const EvalArgs& a);
 // Rosenbrock 16 < D <= 32, Leapfrog: two lanes per chain (config C3), kernels_lane2.hip
 bool lane2_applies(const IterArgs& a);
 int lane2_hmc_iter(const IterArgs& a);
+// how many consecutive iterations of pbbi_hmc_run one call of route_hmc may cover for these arguments
+// (1 = the path has no fused form); lane_fused_iterations: kernels_lane.hip
+int lane_fused_iterations(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
 bool sepn_applies(const IterArgs& a);
 int sepn_hmc_iter(const IterArgs& a);

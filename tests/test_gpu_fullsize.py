@@ -189,7 +189,8 @@ def test_c5_full_size_hmc_run_vs_oracle(P, lib, ragged):
 #   compat:              the OLD POSITION          (src/HMC.py:176)
 #   non-compat, Philox:  the draw parked in the momentum slab before the trajectory
 #   non-compat, upload:  p_in re-loaded
-# h = 0.5, L = 4 rejects 40-60 % of the chains; the uploaded mode also forces u[::3] = 1.5.
+# h = 0.5 (uploaded draws, where u[::3] = 1.5 forces rejections too) / 0.7 (in-kernel draws), L = 4:
+# 40-70 % of the chains reject.
 # ---------------------------------------------------------------------------------------------
 def _stress_problem(D, zero_mean):
     rs = np.random.RandomState(D)
@@ -239,7 +240,7 @@ def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, 
 def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat, method):
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
-    N, h, L, S, seed, chain0, iter0 = 333, 0.5, 4, 3, 11, 77, 5
+    N, h, L, S, seed, chain0, iter0 = 333, 0.7, 4, 3, 11, 77, 5  # 40-67 % rejects in every case
     Pm, mu = _stress_problem(D, zero_mean)
     pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
     op = orc.pot_gauss_dense(mu, Pm, 0.25)

@@ -52,7 +52,7 @@ void run(const char* name, int waves_per_simd, int iters) {
 }
 
 int main() {
-    for (int w : {1, 3}) run<double, 0>("fp64 fma", w, 100000);
+    for (int w : {1, 2, 3, 4, 6}) run<double, 0>("fp64 fma", w, 100000);
     for (int w : {1, 3}) run<double, 1>("fp64 mul", w, 100000);
     for (int w : {1, 3}) run<double, 2>("fp64 add", w, 100000);
     for (int w : {1, 3}) run<float, 0>("fp32 fma", w, 100000);
