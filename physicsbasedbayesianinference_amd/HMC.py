@@ -37,6 +37,86 @@ from .integrator import Leapfrog, StormerVerlet, mass_or_none, resolve_potential
 
 __all__ = ["HMC"]
 
+
+class _HostDrawPipeline:
+    """rng="numpy": the reference's stream (src/ensemble.py:88-91, src/HMC.py:168) is NumPy's global
+    legacy RandomState -- sequential by construction, drawn on the host.  A producer thread draws
+    iteration i+1 (NumPy releases the GIL while it generates), stages it in pinned memory and starts
+    the H2D copy on a side stream while the main thread launches iteration i; three slots.  The
+    consumption ORDER of the global stream is exactly the reference's: only the producer draws."""
+
+    class Slot:
+        pass
+
+    def __init__(self, draw, S, D, N, device, np_dtype, depth=3):
+        import queue
+        import threading
+        from ._device import dev, torch, torch_dtype
+        t = torch()
+        self.t, self.S, self.draw = t, int(S), draw
+        self.draw_seconds = 0.0
+        self.ready = queue.Queue()
+        self.error = None
+        self.thread = None
+        self.stop = False
+        if self.S == 0:
+            return
+        self.side = t.cuda.Stream(device=dev(device))
+        self.main = t.cuda.current_stream(dev(device))
+        td = torch_dtype(np_dtype)
+        self.slots = []
+        for _ in range(min(depth, self.S)):
+            s = self.Slot()
+            s.pin_p = t.empty((D, N), dtype=td, pin_memory=True)
+            s.pin_u = t.empty((N,), dtype=td, pin_memory=True)
+            s.p = t.empty((D, N), dtype=td, device=dev(device))
+            s.u = t.empty((N,), dtype=td, device=dev(device))
+            s.uploaded = t.cuda.Event()
+            s.consumed = None
+            self.slots.append(s)
+        self.thread = threading.Thread(target=self._produce, daemon=True)
+        self.thread.start()
+
+    def _produce(self):
+        import time
+        t = self.t
+        try:
+            for i in range(self.S):
+                if self.stop:  # the consumer gave up (an error in a launch): leave the rest of the stream undrawn
+                    return
+                s = self.slots[i % len(self.slots)]
+                t0 = time.perf_counter()
+                p, u = self.draw(i)
+                self.draw_seconds += time.perf_counter() - t0
+                if s.consumed is not None:
+                    s.consumed.synchronize()   # the kernel that read this slot's device buffers is done
+                s.pin_p.copy_(t.from_numpy(np.ascontiguousarray(p)))   # also converts float64 -> the handle's dtype
+                s.pin_u.copy_(t.from_numpy(np.ascontiguousarray(u)))
+                with t.cuda.stream(self.side):
+                    s.p.copy_(s.pin_p, non_blocking=True)
+                    s.u.copy_(s.pin_u, non_blocking=True)
+                    s.uploaded.record(self.side)
+                self.ready.put(s)
+        except BaseException as e:  # surfaces in acquire()
+            self.error = e
+            self.ready.put(None)
+
+    def acquire(self):
+        s = self.ready.get()
+        if s is None:
+            raise self.error
+        self.main.wait_event(s.uploaded)
+        return s
+
+    def release(self, s):
+        s.consumed = self.t.cuda.Event()
+        s.consumed.record(self.main)
+
+    def close(self):
+        self.stop = True
+        if self.thread is not None:
+            self.thread.join()
+
 # adaptStepSize's Philox key = seed ^ this (the sampling run keeps `seed`)
 WARMUP_SEED_MASK = 0xA5A55A5ADA7A0001
 
@@ -182,22 +262,35 @@ class HMC:
             else:
                 self.integrator.q = ens.q = host_stream.positions(qStd)
             q_prev = as_device(self.integrator.q, dev, dt)
-            for i in range(S):
+
+            def draw(i):
                 if self.verbose and i % 100 == 0:
                     print("HMC iteration ", i + 1)                           # :151-152
                 if host_stream is None:
-                    self.integrator.p = ens.setMomentum(temperature)        # :154
+                    p = ens.setMomentum(temperature)                         # :154
                     u = np.random.uniform(size=N)                            # :168
                 else:
-                    self.integrator.p = ens.p = host_stream.momenta(ens.mass, temperature)
+                    p = ens.p = host_stream.momenta(ens.mass, temperature)
                     u = host_stream.uniforms()
-                pd = as_device(self.integrator.p, dev, dt)
-                ud = as_device(u, dev, dt)
-                _lib.call("pbbi_hmc_iter", pot.handle, self.integrator.method_id,
-                          q_prev.data_ptr(), pd.data_ptr(), ud.data_ptr(), mptr,
-                          samples[i].data_ptr(), momenta[i].data_ptr(), ratio[i].data_ptr(),
-                          reject[i].data_ptr(), N, N, h, L, flags, stream)
-                q_prev = samples[i]
+                self.integrator.p = p
+                return p, u
+            # The NumPy legacy stream can only be drawn in order, on the host (~15 ns per normal):
+            # a producer thread draws iteration i+1 into pinned memory and starts its upload on a
+            # side stream while iteration i's kernel runs (_HostDrawPipeline below).
+            pipe = _HostDrawPipeline(draw, S, D, N, dev, dt)
+            try:
+                for i in range(S):
+                    slot = pipe.acquire()
+                    _lib.call("pbbi_hmc_iter", pot.handle, self.integrator.method_id,
+                              q_prev.data_ptr(), slot.p.data_ptr(), slot.u.data_ptr(), mptr,
+                              samples[i].data_ptr(), momenta[i].data_ptr(), ratio[i].data_ptr(),
+                              reject[i].data_ptr(), N, N, h, L, flags, stream)
+                    pipe.release(slot)
+                    q_prev = samples[i]
+                pipe.stop = False  # every iteration was consumed: nothing to cut short
+            finally:
+                pipe.close()
+            self.host_rng_ms = pipe.draw_seconds * 1e3 / max(S, 1)
         elif rng == "philox":
             kT = float(boltzmannConst * temperature)                         # src/ensemble.py:88
             q_state = empty((D, N), dt, dev)
