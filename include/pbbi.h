@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PBBI_VERSION 100 /* major*100 + minor */
+#define PBBI_VERSION 101 /* major*100 + minor */
 
 enum { PBBI_OK = 0, PBBI_ERR_INVALID = -1, PBBI_ERR_UNSUPPORTED = -2, PBBI_ERR_HIP = -3 };
 enum { PBBI_F64 = 0, PBBI_F32 = 1 };
@@ -76,7 +76,13 @@ enum {
      * integrate this way, the other chain-per-lane kernels ignore it.  Stormer-Verlet under the flag
      * is the same recurrence without the closing half kick and with one more drift (honoured by the
      * separable kernel up to D = 256 and the in-wave Rosenbrock kernel up to D = 128). */
-    PBBI_KDK_FMA = 2
+    PBBI_KDK_FMA = 2,
+    /* Accept test at the temperature of the momentum draw: ratio = exp((oldH - newH) / kT) instead of
+     * the reference's exp(oldH - newH) (src/HMC.py:115 has no beta although src/ensemble.py:88 draws p at
+     * kB*T; the two agree only for T = 1/kB).  With the flag the chains sample exp(-U(q)/kT): the
+     * canonical ensemble at that temperature.  kT is pbbi_hmc_run's argument; uploaded-draw iterations
+     * state it through pbbi_hmc_iter_kt.  Without the flag (default) the reference's test is kept. */
+    PBBI_BETA_ACCEPT = 4
 };
 enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2 };
 
@@ -178,6 +184,13 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
                   uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags,
                   void* stream);
 
+/* pbbi_hmc_iter for momenta drawn at kT = boltzmannConst*temperature (src/ensemble.py:88): identical
+ * to it unless flags has PBBI_BETA_ACCEPT, which needs kT for its accept test. */
+int pbbi_hmc_iter_kt(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                     const void* u_in, const void* mass, void* q_out, void* p_out, void* ratio_out,
+                     uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags, double kT,
+                     void* stream);
+
 /* S iterations of the same loop with momentum and uniforms drawn in-kernel
  * (RNG contract above): iteration i uses draw index iter0+i, chain n uses the
  * global index chain0+n, p = sqrt(mass*kT) * z  (src/ensemble.py:88-91 with
@@ -227,6 +240,22 @@ int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dt
  * (HMC.rhat in the Python layer); S >= 2. */
 int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
                        void* chain_mean_out, void* chain_var_out, void* stream);
+
+/* ---- ensemble weights ----------------------------------------------
+ * Normalised canonical weights of an ensemble from its per-chain Hamiltonians (pbbi_energy),
+ *     w_n = exp(-beta (H_n - H_min)) / sum_m exp(-beta (H_m - H_min)),
+ * the normalised form of HMC.getWeights (src/HMC.py:86-104; the reference's commented-out
+ * Ensemble.setWeights, src/ensemble.py:52-61) -- computed on the device in three steps so that a
+ * SHARDED ensemble can all-reduce the two scalars in between (MIN of *min_out, SUM of *sum_out; both
+ * are device doubles):
+ *   pbbi_reduce_min        *min_out = min_n x[n]  (NaNs are skipped; +inf for N == 0)
+ *   pbbi_canonical_weights w_out[n] = exp(-beta (H[n] - *hmin)),  *sum_out = sum_n w_out[n]
+ *   pbbi_scale_inverse     w[n] /= *sum
+ * Reductions are two-stage and deterministic (no atomics).  x / H / w are of `dtype`. */
+int pbbi_reduce_min(const void* x, int64_t N, int dtype, int device, double* min_out, void* stream);
+int pbbi_canonical_weights(const void* H, int64_t N, double beta, const double* hmin, int dtype,
+                           int device, void* w_out, double* sum_out, void* stream);
+int pbbi_scale_inverse(void* w, int64_t N, const double* sum, int dtype, int device, void* stream);
 
 #ifdef __cplusplus
 }

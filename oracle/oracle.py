@@ -21,6 +21,7 @@ _LIB = None
 HARMONIC, GAUSS_DIAG, GAUSS_DENSE, ROSENBROCK, CUSTOM = 0, 1, 2, 3, 4
 LEAPFROG, STORMER_VERLET = 0, 1
 COMPAT_P_FROM_OLDQ = 1
+BETA_ACCEPT = 4
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
 METHODS = {"Leapfrog": LEAPFROG, "Stormer-Verlet": STORMER_VERLET}
 
@@ -206,9 +207,9 @@ def weights_ratio(pot, newQ, newP, oldQ, oldP, mass=None):
     return r
 
 
-def hmc_iter(pot, method, q, p, u, mass, h, L, compat=COMPAT_P_FROM_OLDQ):
+def hmc_iter(pot, method, q, p, u, mass, h, L, compat=COMPAT_P_FROM_OLDQ, beta=1.0):
     """One getSamples iteration, in place on q (state) and p (drawn momentum).
-    Returns (ratio, reject_mask)."""
+    Returns (ratio, reject_mask).  beta != 1: the build's PBBI_BETA_ACCEPT accept test."""
     st, keep, D = _cpot(pot)
     Dq, N = _dn(q)
     assert _dn(p) == (Dq, N) and Dq == D
@@ -217,9 +218,9 @@ def hmc_iter(pot, method, q, p, u, mass, h, L, compat=COMPAT_P_FROM_OLDQ):
     m = _mass(mass, N)
     ratio = np.empty(N)
     rej = np.empty(N, dtype=np.uint8)
-    rc = lib().oracle_hmc_iter(C.byref(st), C.c_int(METHODS.get(method, method)), _ptr(q), _ptr(p),
-                               _ptr(u), _ptr(m), C.c_int64(N), C.c_int64(N), C.c_double(h),
-                               C.c_int(L), C.c_int(compat), _ptr(ratio), _ptr(rej))
+    rc = lib().oracle_hmc_iter_beta(C.byref(st), C.c_int(METHODS.get(method, method)), _ptr(q), _ptr(p),
+                                    _ptr(u), _ptr(m), C.c_int64(N), C.c_int64(N), C.c_double(h),
+                                    C.c_int(L), C.c_int(compat), C.c_double(beta), _ptr(ratio), _ptr(rej))
     assert rc == 0
     return ratio, rej.astype(bool)
 

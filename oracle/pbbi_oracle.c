@@ -33,7 +33,7 @@
 enum { POT_HARMONIC = 0, POT_GAUSS_DIAG = 1, POT_GAUSS_DENSE = 2, POT_ROSENBROCK = 3, POT_CUSTOM = 4 };
 enum { METHOD_LEAPFROG = 0, METHOD_STORMER_VERLET = 1 };
 /* compat flag bit 0: reproduce src/HMC.py:176 (rejected momentum <- oldQ) */
-enum { COMPAT_P_FROM_OLDQ = 1 };
+enum { COMPAT_P_FROM_OLDQ = 1, BETA_ACCEPT = 4 /* include/pbbi.h: PBBI_BETA_ACCEPT */ };
 
 typedef struct {
     int kind;
@@ -340,9 +340,22 @@ int oracle_weights_ratio(const oracle_pot* P, const double* newQ, const double* 
  *   - rejected: q <- oldQ (:175) and p <- oldQ (:176, reference bug) when
  *     compat & COMPAT_P_FROM_OLDQ, else p <- oldP.
  */
+/* beta: factor on (oldH - newH) in the accept test.  1.0 is the reference (src/HMC.py:115 has no
+ * temperature); 1/kT is the build's PBBI_BETA_ACCEPT (include/pbbi.h), which matches the momentum
+ * draw of src/ensemble.py:88.  x * 1.0 == x bit for bit, so beta = 1 restates the reference exactly. */
+int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, const double* u,
+                         const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
+                         double beta, double* ratio_out, unsigned char* reject_out);
+
 int oracle_hmc_iter(const oracle_pot* P, int method, double* q, double* p, const double* u,
                     const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
                     double* ratio_out, unsigned char* reject_out) {
+    return oracle_hmc_iter_beta(P, method, q, p, u, mass, N, ldn, h, L, compat, 1.0, ratio_out, reject_out);
+}
+
+int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, const double* u,
+                         const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
+                         double beta, double* ratio_out, unsigned char* reject_out) {
     const int D = P->D;
     if (D > ORACLE_MAXD || L < 0) return -1;
 #pragma omp parallel
@@ -364,7 +377,7 @@ int oracle_hmc_iter(const oracle_pot* P, int method, double* q, double* p, const
             for (int d = 0; d < D; ++d) tmp[d] = -pc[d]; /* p = -p  :164 */
             const double oldH = hamiltonian(P, oq, op, m);
             const double newH = hamiltonian(P, qc, tmp, m);
-            const double ratio = exp(oldH - newH);                 /* :115 */
+            const double ratio = exp((oldH - newH) * beta);        /* :115 */
             const double acc = (1.0 < ratio || ratio != ratio) ? ((ratio != ratio) ? ratio : 1.0)
                                                                : ratio; /* np.minimum(1, ratio) */
             const int reject = (u[n] > acc); /* False when acc is NaN  :173 */
@@ -494,9 +507,10 @@ int oracle_hmc_run_philox(const oracle_pot* P, int method, double* q, const doub
     for (int i = 0; i < S && rc == 0; ++i) {
         oracle_philox_normal(seed, STREAM_MOMENTUM, iter0 + i, chain0, D, N, ldn, 1.0, pstd, p);
         oracle_philox_uniform(seed, iter0 + i, chain0, N, u);
-        rc = oracle_hmc_iter(P, method, q, p, u, mass, N, ldn, h, L, compat,
-                             ratio_out ? ratio_out + (size_t)i * N : NULL,
-                             reject_out ? reject_out + (size_t)i * N : NULL);
+        rc = oracle_hmc_iter_beta(P, method, q, p, u, mass, N, ldn, h, L, compat,
+                                  (compat & BETA_ACCEPT) ? 1.0 / kT : 1.0,
+                                  ratio_out ? ratio_out + (size_t)i * N : NULL,
+                                  reject_out ? reject_out + (size_t)i * N : NULL);
         for (int d = 0; d < D; ++d) {
             memcpy(samples_out + ((size_t)i * D + d) * N, q + (size_t)d * ldn, sizeof(double) * N);
             if (momenta_out)

@@ -123,12 +123,16 @@ WARMUP_SEED_MASK = 0xA5A55A5ADA7A0001
 
 class HMC:
     def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
-                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=None):
+                 method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=None,
+                 beta_accept=False):
         self.ensemble = ensemble
         self.simulTime = simulTime
         self.stepSize = stepSize
         self.density = density
         self.compat = bool(compat)
+        # PBBI_BETA_ACCEPT (include/pbbi.h): accept with exp((oldH - newH) / (kB*T)), the test that
+        # matches the momentum draw at kB*T; default off = the reference's exp(oldH - newH)
+        self.beta_accept = bool(beta_accept)
         # PBBI_KDK_FMA, the throughput form of Leapfrog (include/pbbi.h): default on in the
         # throughput RNG mode, off in the reference-parity mode
         self.kdk_fma = (rng == "philox") if kdk_fma is None else bool(kdk_fma)
@@ -177,6 +181,31 @@ class HMC:
                 raise ValueError(f"expected a ({D}, {N}) array, got {a.shape}")
             out.append(as_device(a, pot.device, pot.dtype))
         return out
+
+    def _flags(self):
+        return ((_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0) |
+                (_lib.BETA_ACCEPT if self.beta_accept else 0))
+
+    def ensembleWeights(self, q, p, temperature=None):
+        """Normalised canonical weights of the ensemble, w_n = exp(-beta H_n) / sum_m exp(-beta H_m)
+        with H = 0.5 p.p/mass + potential(q) (HMC.getWeights, src/HMC.py:86-104, normalised; the
+        reference's commented-out Ensemble.setWeights, src/ensemble.py:52-61) and beta = 1/(kB*T)
+        (beta = 1 when temperature is None).  Energies, the min / sum reductions and the scaling all
+        run on the GPU (pbbi_energy, pbbi_reduce_min, pbbi_canonical_weights, pbbi_scale_inverse);
+        with an initialised torch.distributed group the two scalars are all-reduced, so every rank
+        holds its shard of the weights of the WHOLE ensemble.  Also stored in ensemble.weights."""
+        from . import distributed
+        pot = self._pot
+        N = self.ensemble.numParticles
+        qd, pd = self._upload_state(q, p)
+        md = self._mass()
+        H = empty((N,), pot.dtype, pot.device)
+        _lib.call("pbbi_energy", pot.handle, qd.data_ptr(), pd.data_ptr(),
+                  md.data_ptr() if md is not None else None, N, N, H.data_ptr(), None, stream_ptr(pot.device))
+        beta = 1.0 if temperature is None else 1.0 / float(boltzmannConst * temperature)
+        w = to_numpy(distributed.ensemble_weights(H, beta)[0]).astype(np.float64)
+        self.ensemble.weights = w
+        return w
 
     def _mass(self):
         pot = self._pot
@@ -240,7 +269,7 @@ class HMC:
         seed = self.seed if seed is None else int(seed)
         L = self.integrator.numSteps
         h = float(self.stepSize)
-        flags = (_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0)
+        flags = self._flags()
         dev, dt = pot.device, pot.dtype
         stream = stream_ptr(dev)
 
@@ -262,6 +291,7 @@ class HMC:
             else:
                 self.integrator.q = ens.q = host_stream.positions(qStd)
             q_prev = as_device(self.integrator.q, dev, dt)
+            kT_host = float(boltzmannConst * temperature) if self.beta_accept else 1.0
 
             def draw(i):
                 if self.verbose and i % 100 == 0:
@@ -281,10 +311,10 @@ class HMC:
             try:
                 for i in range(S):
                     slot = pipe.acquire()
-                    _lib.call("pbbi_hmc_iter", pot.handle, self.integrator.method_id,
+                    _lib.call("pbbi_hmc_iter_kt", pot.handle, self.integrator.method_id,
                               q_prev.data_ptr(), slot.p.data_ptr(), slot.u.data_ptr(), mptr,
                               samples[i].data_ptr(), momenta[i].data_ptr(), ratio[i].data_ptr(),
-                              reject[i].data_ptr(), N, N, h, L, flags, stream)
+                              reject[i].data_ptr(), N, N, h, L, flags, kT_host, stream)
                     pipe.release(slot)
                     q_prev = samples[i]
                 pipe.stop = False  # every iteration was consumed: nothing to cut short
@@ -355,7 +385,7 @@ class HMC:
         dev, dt = pot.device, pot.dtype
         stream = stream_ptr(dev)
         kT = float(boltzmannConst * temperature)
-        flags = (_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0)
+        flags = self._flags()
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
         q_state = empty((D, N), dt, dev)
@@ -416,7 +446,7 @@ class HMC:
                   float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
         sharded = torch.distributed.is_available() and torch.distributed.is_initialized()
         h = float(self.stepSize)
-        run_flags = _lib.KDK_FMA if self.kdk_fma else 0  # the same kernels the sampling run will use
+        run_flags = self._flags() & ~_lib.COMPAT_P_FROM_OLDQ  # the same kernels and accept test as the sampling run
         mu, hbar, log_hbar = np.log(10.0 * h), 0.0, 0.0
         for m in range(1, int(iterations) + 1):
             L = max(1, int(self.simulTime / h))

@@ -15,6 +15,7 @@ F64, F32 = 0, 1
 LEAPFROG, STORMER_VERLET = 0, 1
 COMPAT_P_FROM_OLDQ = 1
 KDK_FMA = 2
+BETA_ACCEPT = 4
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
 
 
@@ -55,6 +56,7 @@ PROTOTYPES = {
     "pbbi_energy": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "pbbi_weights_ratio": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "pbbi_hmc_iter": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _vp],
+    "pbbi_hmc_iter_kt": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _d, _vp],
     "pbbi_hmc_run": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64,
                      _u64, _d, _vp],
     "pbbi_philox_normal": [_u64, _i, _u64, _u64, _i, _i64, _i64, _d, _vp, _i, _i, _vp, _vp],
@@ -62,6 +64,9 @@ PROTOTYPES = {
     "pbbi_transpose_sdn_to_dns": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "pbbi_sample_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
     "pbbi_chain_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
+    "pbbi_reduce_min": [_vp, _i64, _i, _i, _vp, _vp],
+    "pbbi_canonical_weights": [_vp, _i64, _d, _vp, _i, _i, _vp, _vp, _vp],
+    "pbbi_scale_inverse": [_vp, _i64, _vp, _i, _i, _vp],
 }
 
 _lib = None

@@ -455,7 +455,7 @@ template <typename T>
 __global__ void k_big_decide(const T* pp_old_part, const T* pp_new_part, int n_sq_parts,
                              const T* xg_old_part, const T* xg_new_part, int n_xg_parts,
                              const T* mass, const T* u_in, int rng, uint64_t seed, uint64_t iter,
-                             uint64_t chain0, T cst, int64_t N, T* ratio_out, uint8_t* reject) {
+                             uint64_t chain0, T cst, T beta, int64_t N, T* ratio_out, uint8_t* reject) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     T po = T(0), pn = T(0), xo = T(0), xn = T(0);
@@ -470,7 +470,7 @@ __global__ void k_big_decide(const T* pp_old_part, const T* pp_new_part, int n_s
     const T m = mass ? mass[n] : T(1);
     const T oldH = T(0.5) * po / m + (T(0.5) * xo + cst);
     const T newH = T(0.5) * pn / m + (T(0.5) * xn + cst);
-    const T ratio = exp(oldH - newH);
+    const T ratio = exp((oldH - newH) * beta);
     const T u = rng ? (T)rng_uniform(seed, iter, chain0 + (uint64_t)n) : u_in[n];
     const bool rej = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
     reject[n] = rej ? 1 : 0;
@@ -641,7 +641,8 @@ int run_hmc(const IterArgs& a) {
                        (int64_t)N, D, N, SQ_ROWS, pp_new);
     hipLaunchKernelGGL(k_big_decide<T>, g1, b1, 0, st, (const T*)pp_old, (const T*)pp_new, n_sq,
                        (const T*)xg_old, xg_fin, n_xg, (const T*)a.mass, (const T*)a.u_in,
-                       a.rng, a.seed, a.iter, a.chain0, (T)pot->cst, N, (T*)a.ratio_out, rej);
+                       a.rng, a.seed, a.iter, a.chain0, (T)pot->cst, (T)pbbi_accept_beta(a.flags, a.kT), N,
+                       (T*)a.ratio_out, rej);
     hipLaunchKernelGGL(k_big_select<T>, grid2d(N, D), b1, 0, st, (const T*)a.q_in, a.ldn_in, qcur,
                        (const T*)vh, (const T*)pdraw, (int64_t)N, (const uint8_t*)rej,
                        (a.flags & PBBI_COMPAT_P_FROM_OLDQ) ? 1 : 0, (T*)a.q_out, (T*)a.p_out,

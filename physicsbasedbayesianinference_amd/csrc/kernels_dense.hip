@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
         xg_new = chain_sum(xg_new);
         const double oldH = 0.5 * pp_old / m + (0.5 * xg_old + prm.cst);
         const double newH = 0.5 * pp_new / m + (0.5 * xg_new + prm.cst);
-        const double ratio = exp(oldH - newH);
+        const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));
         const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
         const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
         bool store_p = have_pout;
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         }
         const double newH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
         STAMP(40);
-        const double ratio = exp(oldH - newH);
+        const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));
         const double u = rng ? rng_uniform(prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc))
                              : prm.u_in[n0 + cc];
         const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));

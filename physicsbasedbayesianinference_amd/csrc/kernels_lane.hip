@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
     integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
     const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);  // p -> -p leaves dot(p,p) unchanged
-    const T ratio = exp(oldH - newH);                        // src/HMC.py:115
+    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
     const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
     if (reject) {

@@ -303,7 +303,7 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
         if (!half) newH = o;
     }
     RSTAMP(n0 / CHAINS_PER_BLOCK, 3);
-    const double ratio = exp(oldH - newH);  // src/HMC.py:115
+    const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     if (reject) {

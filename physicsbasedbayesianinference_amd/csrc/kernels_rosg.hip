@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
         for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
     }
     const double newH = hamiltonian();
-    const double ratio = exp(oldH - newH);  // src/HMC.py:115
+    const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     if (reject) {

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64 * GMAX, (GMAX <= 4 ? 3 : 1)) k_rosn_hmc(Ros
     __syncthreads();
     double dsum = 0.0;
     for (int g = 0; g < G; ++g) dsum += dH[g * 64 + c];
-    const double ratio = exp(dsum);  // src/HMC.py:115
+    const double ratio = exp(dsum * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     if (reject) {

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     __syncthreads();
     double dsum = 0.0;
     for (int g = 0; g < G; ++g) dsum += dH[g][c];
-    const double ratio = exp(dsum);  // src/HMC.py:115
+    const double ratio = exp(dsum * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     // back to positions: q = x + mu, or the untouched old position for a rejected chain (:175)

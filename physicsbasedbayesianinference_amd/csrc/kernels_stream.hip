@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(SB) k_stream_hmc(HmcPrm<T> prm, SPot<T> pot) {
     const T oldH = T(0.5) * pp / m + U0;
     trajectory<T, K, METHOD, UNIT>(pot, wq, wv, wa, ld, m, prm.h, prm.L);
     const T newH = final_energy<T, K, METHOD, UNIT>(pot, wq, wv, wa, ld, m, prm.h);
-    const T ratio = exp(oldH - newH);  // src/HMC.py:115
+    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
     const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
 

@@ -261,6 +261,78 @@ __global__ void k_chain_moments(const T* __restrict__ x, int S, int D, int64_t N
     if (var_out) var_out[(int64_t)d * N + n] = (T)(m2 / (double)(S - 1));
 }
 
+// ensemble weights: stage 1 of a deterministic two-stage reduction (MODE 0: min of x, NaNs skipped;
+// MODE 1: w = exp(-beta (H - hmin)) stored, partial sums of w)
+template <typename T, int MODE>
+__global__ void k_weights_partial(const T* __restrict__ x, int64_t N, double beta, const double* hmin,
+                                  T* w_out, double* __restrict__ part) {
+    const double h0 = MODE == 1 ? *hmin : 0.0;
+    double acc = MODE == 0 ? INFINITY : 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)x[n];
+        if constexpr (MODE == 0) {
+            if (v < acc) acc = v;  // false for NaN
+        } else {
+            const double w = exp(-beta * (v - h0));
+            w_out[n] = (T)w;
+            acc += (double)(T)w;   // the sum of what is stored
+        }
+    }
+    __shared__ double r[256];
+    r[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double o = r[threadIdx.x + s];
+            if constexpr (MODE == 0) { if (o < r[threadIdx.x]) r[threadIdx.x] = o; }
+            else r[threadIdx.x] += o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = r[0];
+}
+
+template <int MODE>
+__global__ void k_weights_final(const double* __restrict__ part, int n_part, double* out) {
+    double acc = MODE == 0 ? INFINITY : 0.0;
+    for (int i = 0; i < n_part; ++i) {  // fixed order
+        if constexpr (MODE == 0) { if (part[i] < acc) acc = part[i]; }
+        else acc += part[i];
+    }
+    *out = acc;
+}
+
+template <typename T>
+__global__ void k_scale_inverse(T* w, int64_t N, const double* sum) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) w[n] = (T)((double)w[n] / *sum);
+}
+
+template <int MODE>
+int weights_reduce(const void* x, int64_t N, double beta, const double* hmin, int dtype, int device,
+                   void* w_out, double* out, hipStream_t st) {
+    if (N < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad N");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    if (!out || (N > 0 && !x) || (MODE == 1 && (!hmin || (N > 0 && !w_out))))
+        return pbbi_fail(PBBI_ERR_INVALID, "a pointer is NULL");
+    DeviceGuard guard(device);
+    const int n_part = (int)((N + 255) / 256 < 256 ? (N + 255) / 256 : 256);
+    double* part = nullptr;
+    PBBI_HIP(hipMallocAsync((void**)&part, sizeof(double) * (n_part > 0 ? n_part : 1), st));
+    if (n_part > 0) {
+        if (dtype == PBBI_F64)
+            hipLaunchKernelGGL((k_weights_partial<double, MODE>), dim3(n_part), dim3(256), 0, st,
+                               (const double*)x, N, beta, hmin, (double*)w_out, part);
+        else
+            hipLaunchKernelGGL((k_weights_partial<float, MODE>), dim3(n_part), dim3(256), 0, st,
+                               (const float*)x, N, beta, hmin, (float*)w_out, part);
+    }
+    hipLaunchKernelGGL((k_weights_final<MODE>), dim3(1), dim3(1), 0, st, (const double*)part, n_part, out);
+    PBBI_HIP(hipGetLastError());
+    PBBI_HIP(hipFreeAsync(part, st));
+    return PBBI_OK;
+}
+
 }  // namespace
 
 // ======================================================================= library
@@ -467,6 +539,23 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
     return route_hmc(a);
 }
 
+int pbbi_hmc_iter_kt(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                     const void* u_in, const void* mass, void* q_out, void* p_out, void* ratio_out,
+                     uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags, double kT,
+                     void* stream) {
+    if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    if ((!q_in || !p_in || !u_in || !q_out) && N > 0)
+        return pbbi_fail(PBBI_ERR_INVALID, "q_in / p_in / u_in / q_out must be non-NULL");
+    if (!(kT > 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be > 0");
+    DeviceGuard guard(pot->device);
+    IterArgs a{};
+    a.pot = pot; a.method = method; a.q_in = q_in; a.p_in = p_in; a.u_in = u_in; a.mass = mass;
+    a.q_out = q_out; a.p_out = p_out; a.ratio_out = ratio_out; a.reject_out = reject_out;
+    a.N = N; a.ldn_in = ldn; a.ldn_out = ldn; a.h = h; a.L = L; a.flags = flags;
+    a.rng = 0; a.kT = kT; a.stream = (hipStream_t)stream;
+    return route_hmc(a);
+}
+
 int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
                  void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
                  int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
@@ -477,6 +566,8 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
     if (!samples_out && momenta_out)
         return pbbi_fail(PBBI_ERR_INVALID, "momenta_out without samples_out (burn-in records nothing)");
     if (!(kT >= 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be >= 0");
+    if ((flags & PBBI_BETA_ACCEPT) && !(kT > 0.0))
+        return pbbi_fail(PBBI_ERR_INVALID, "PBBI_BETA_ACCEPT needs kT > 0");
     // the Philox counter carries the low 32 bits of the iteration index (include/pbbi.h): a run that
     // crosses 2^32 would silently repeat the draws of iterations 0, 1, ...
     if (iter0 > UINT32_MAX || iter0 + (uint64_t)S > (uint64_t)UINT32_MAX + 1)
@@ -647,6 +738,31 @@ int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dty
         hipLaunchKernelGGL(k_chain_moments<float>, grid, block, 0, (hipStream_t)stream,
                            (const float*)samples_sdn, S, D, N, (float*)chain_mean_out,
                            (float*)chain_var_out);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// ============================================================== ensemble weights
+int pbbi_reduce_min(const void* x, int64_t N, int dtype, int device, double* min_out, void* stream) {
+    return weights_reduce<0>(x, N, 0.0, nullptr, dtype, device, nullptr, min_out, (hipStream_t)stream);
+}
+
+int pbbi_canonical_weights(const void* H, int64_t N, double beta, const double* hmin, int dtype,
+                           int device, void* w_out, double* sum_out, void* stream) {
+    return weights_reduce<1>(H, N, beta, hmin, dtype, device, w_out, sum_out, (hipStream_t)stream);
+}
+
+int pbbi_scale_inverse(void* w, int64_t N, const double* sum, int dtype, int device, void* stream) {
+    if (N < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad N");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    if (!sum || (N > 0 && !w)) return pbbi_fail(PBBI_ERR_INVALID, "a pointer is NULL");
+    if (N == 0) return PBBI_OK;
+    DeviceGuard guard(device);
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_scale_inverse<double>, grid, block, 0, (hipStream_t)stream, (double*)w, N, sum);
+    else
+        hipLaunchKernelGGL(k_scale_inverse<float>, grid, block, 0, (hipStream_t)stream, (float*)w, N, sum);
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
             }
     }
     const T newH = T(0.5) * pp1 / m + c.potential();
-    const T ratio = exp(oldH - newH);  // src/HMC.py:115
+    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
     const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
 
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
 #pragma unroll
     for (int j = 0; j < RD; ++j) pp1 += v[j] * v[j];
     const T newH = T(0.5) * pp1 / m + user::potential(q, RD, prm.prm);
-    const T ratio = exp(oldH - newH);  // src/HMC.py:115
+    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
     if (reject) {
 #pragma unroll

@@ -65,6 +65,13 @@ struct DeviceGuard {  // make the handle's device current for the duration of a 
     }
 };
 
+// PBBI_BETA_ACCEPT: factor on (oldH - newH) in the accept test.  1.0 (exact: the product then has the
+// bits of the difference) reproduces src/HMC.py:115; 1/kT is the test that matches the momentum draw
+// of src/ensemble.py:88.
+__host__ __device__ inline double pbbi_accept_beta(int flags, double kT) {
+    return (flags & PBBI_BETA_ACCEPT) ? 1.0 / kT : 1.0;
+}
+
 int pbbi_num_cus(int device);  // compute units of a device (cached), pbbi_api.hip
 // ---- launch descriptors passed between api and kernel TUs ---------------------
 struct IterArgs {

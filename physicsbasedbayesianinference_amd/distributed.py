@@ -97,12 +97,35 @@ def ensemble_weights(H_local, beta=1.0, group=None):
         w_n = exp(-beta (H_n - H_min)) / Z,   Z = sum over ALL ranks' chains
     with the shift by the global minimum so that exp never underflows.  The first cross-chain
     reductions of the path: one all-reduce(MIN) and one all-reduce(SUM) of a scalar each (RCCL on
-    CUDA tensors, gloo on CPU tensors); without a process group the sums are local.
+    CUDA tensors, gloo on CPU tensors); without a process group the sums are local.  A CUDA tensor
+    is reduced by the library's own kernels, a CPU tensor (the gloo tests) by torch on the host.
     Returns (w_local, log_Z) with log_Z = log sum_n exp(-beta H_n)."""
     import torch
     dist = _dist()
-    H = torch.as_tensor(H_local, dtype=torch.float64)
     sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if torch.is_tensor(H_local) and H_local.is_cuda:
+        # device tensors: the library's reduction kernels (include/pbbi.h, "ensemble weights"); only
+        # the two all-reduced scalars are torch's business
+        from . import _lib
+        from ._device import stream_ptr
+        H = H_local.contiguous()
+        if H.dtype not in (torch.float64, torch.float32):
+            H = H.double()
+        code = _lib.F64 if H.dtype == torch.float64 else _lib.F32
+        dev, n, st = H.device.index, H.numel(), stream_ptr(H.device.index)
+        hmin = torch.empty(1, dtype=torch.float64, device=H.device)
+        z = torch.empty(1, dtype=torch.float64, device=H.device)
+        w = torch.empty_like(H)
+        _lib.call("pbbi_reduce_min", H.data_ptr(), n, code, dev, hmin.data_ptr(), st)
+        if sharded:
+            dist.all_reduce(hmin, op=dist.ReduceOp.MIN, group=group)
+        _lib.call("pbbi_canonical_weights", H.data_ptr(), n, float(beta), hmin.data_ptr(), code, dev,
+                  w.data_ptr(), z.data_ptr(), st)
+        if sharded:
+            dist.all_reduce(z, op=dist.ReduceOp.SUM, group=group)
+        _lib.call("pbbi_scale_inverse", w.data_ptr(), n, z.data_ptr(), code, dev, st)
+        return w, float(torch.log(z) - beta * hmin)
+    H = torch.as_tensor(H_local, dtype=torch.float64)
     hmin = torch.min(H).reshape(1) if H.numel() else torch.full((1,), float("inf"), dtype=torch.float64,
                                                                   device=H.device)
     if sharded:

@@ -1459,3 +1459,126 @@ def test_hmc_from_density_only(P):
     assert np.array_equal(hmc.reject_masks, g["reject_mask"])
     assert scaled_err(samples, g["samples"]) <= RTOL_GOLDEN
     assert scaled_err(momenta, g["momenta"]) <= RTOL_GOLDEN
+
+
+# ------------------------------------------------------------------ beta in the accept test, ensemble weights
+@pytest.mark.parametrize("case", ["lane_diag5", "dense24", "ros32", "diag64_kdk", "big200", "stream_ros70"])
+@pytest.mark.parametrize("rng", ["upload", "philox"])
+def test_beta_accept_vs_oracle(P, lib, case, rng):
+    """PBBI_BETA_ACCEPT: ratio = exp((oldH - newH) / kT) in every kernel family, against the oracle's
+    hmc_iter(beta=1/kT) on the same draws; without the flag the reference's exp(oldH - newH)
+    (src/HMC.py:115) whatever kT is."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(11)
+    kdk = case.endswith("_kdk")
+    if case == "lane_diag5":
+        D, mu, prec = 5, rs.standard_normal(5), rs.uniform(0.5, 2, 5)
+        pot, op, h = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec), 0.4
+    elif case in ("dense24", "big200"):
+        D = 24 if case == "dense24" else 200
+        A = rs.standard_normal((D, D))
+        Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+        Pm = 0.5 * (Pm + Pm.T)
+        pot, op, h = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm), 0.4
+    elif case == "ros32":
+        D, pot, op, h = 32, P.Rosenbrock(32), orc.pot_rosenbrock(32), 0.13
+    elif case == "stream_ros70":
+        D, pot, op, h = 70, P.Rosenbrock(70), orc.pot_rosenbrock(70), 0.12
+    else:
+        D, mu, prec = 64, rs.standard_normal(64), rs.uniform(0.5, 2, 64)
+        pot, op, h = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec), 0.3
+    N, L, kT, seed = 300, 6, 2.5, 3
+    tol = 0.0 if case in ("lane_diag5", "ros32", "stream_ros70") else 1e-11
+    st = stream_ptr(0)
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.BETA_ACCEPT | (lib.KDK_FMA if kdk else 0)
+    q0 = (1.0 if "ros" in case else 0.0) + 0.5 * rs.standard_normal((D, N))
+    qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
+    ro, rj = empty((N,), np.float64, 0), empty((N,), np.uint8, 0)
+    qd = as_device(q0, 0, np.float64)
+    if rng == "upload":
+        p = rs.standard_normal((D, N)) * np.sqrt(kT)
+        u = rs.uniform(size=N)
+        pd, ud = as_device(p, 0, np.float64), as_device(u, 0, np.float64)
+        lib.call("pbbi_hmc_iter_kt", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(), None,
+                 qo.data_ptr(), po.data_ptr(), ro.data_ptr(), rj.data_ptr(), N, N, h, L, flags, kT, st)
+    else:
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, 0, 0, D, N, np.sqrt(kT))
+        u = device_uniform(lib, seed, 0, 0, N)
+        lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), None, qo.data_ptr(), po.data_ptr(), rj.data_ptr(),
+                 ro.data_ptr(), N, N, h, L, 1, flags, seed, 0, 0, kT, st)
+    torch.cuda.synchronize()
+    q_or, p_or = q0.copy(), p.copy()
+    r_or, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, None, h, L, beta=1.0 / kT)
+    r_ref, rej_ref = orc.hmc_iter(op, "Leapfrog", q0.copy(), p.copy(), u, None, h, L)      # reference test
+    assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
+    assert rej_or.any() and not np.array_equal(r_or, r_ref, equal_nan=True)
+    if "ros" not in case:  # (Rosenbrock trajectories are either near-exact or diverged: the same decisions)
+        assert not np.array_equal(rej_or, rej_ref)                # the flag changes decisions at kT != 1
+    if tol == 0.0:
+        assert np.array_equal(to_numpy(qo), q_or) and np.array_equal(to_numpy(po), p_or)
+    else:
+        assert scaled_err(to_numpy(qo), q_or) <= tol and scaled_err(to_numpy(po), p_or) <= tol
+    fin = np.isfinite(r_or) & (r_or > 0)
+    assert np.max(np.abs(np.log(to_numpy(ro)[fin]) - np.log(r_or[fin]))) < 1e-8
+
+
+def test_tempered_sampling_moments(P):
+    """HMC(..., beta_accept=True) at T = 2.5/kB samples exp(-U/kT): for a Gaussian potential with
+    covariance Sigma the draws have covariance kT*Sigma; the reference's test (beta = 1 while p is drawn
+    at kT, src/HMC.py:115 vs src/ensemble.py:88) does not."""
+    D, N, kT = 6, 8192, 2.5
+    rs = np.random.RandomState(5)
+    A = rs.standard_normal((D, D))
+    cov = A @ A.T / D + 0.5 * np.eye(D)
+    mu = rs.standard_normal(D)
+    pot = P.GaussianDense(mu, cov=cov)
+    out = {}
+    for beta_accept in (True, False):
+        hmc = P.HMC(P.Ensemble(D, N), 1.8, 0.6, None, potential=pot, rng="philox", seed=2, verbose=False,
+                    beta_accept=beta_accept)   # a coarse step: 8-18 % of the proposals are rejected
+        assert hmc.integrator.numSteps == 3
+        s, _ = hmc.getSamples(40, kT / kB, 1.0, device_output=True)
+        x = s[:, :, 20:].permute(0, 2, 1).reshape(D, -1).double()
+        out[beta_accept] = (x.mean(1).cpu().numpy(), torch_cov(x))
+    mean, c = out[True]
+    assert np.max(np.abs(mean - mu)) < 0.03
+    assert np.max(np.abs(c - kT * cov)) < 0.02 * kT * np.max(np.abs(cov))
+    # the reference's accept test at this temperature: visibly not the canonical ensemble at kT
+    # (oracle, same draws: 0.5 % against 7 % off)
+    assert np.max(np.abs(out[False][1] - kT * cov)) > 0.04 * kT * np.max(np.abs(cov))
+
+
+def torch_cov(x):
+    xc = x - x.mean(1, keepdim=True)
+    return (xc @ xc.T / (x.shape[1] - 1)).cpu().numpy()
+
+
+def test_ensemble_weights_on_device(P, lib):
+    """pbbi_reduce_min / pbbi_canonical_weights / pbbi_scale_inverse and HMC.ensembleWeights against
+    NumPy: w = exp(-beta (H - Hmin)) / sum, NaN energies skipped by the minimum, fp32 handles too."""
+    import torch
+    from physicsbasedbayesianinference_amd import distributed
+    rs = np.random.RandomState(1)
+    for N in (1, 257, 70001):
+        H = rs.standard_normal(N) * 30 + 1000.0
+        for dtype in (torch.float64, torch.float32):
+            Hd = torch.tensor(H, dtype=dtype, device="cuda")
+            w, logz = distributed.ensemble_weights(Hd, beta=0.7)
+            Hh = Hd.cpu().double().numpy()
+            e = np.exp(-0.7 * (Hh - Hh.min()))
+            assert w.dtype == dtype
+            assert np.allclose(w.cpu().double().numpy(), e / e.sum(), rtol=1e-12 if dtype == torch.float64 else 2e-6)
+            assert abs(logz - (np.log(e.sum()) - 0.7 * Hh.min())) < 1e-9 * abs(logz) + 1e-6
+    D, N = 3, 500
+    pot = P.Harmonic(np.array([2.0, 3.0, 0.5]))
+    ens = P.Ensemble(D, N)
+    ens.mass = 1.0 + np.arange(N) % 3
+    hmc = P.HMC(ens, 1.0, 0.1, None, potential=pot, verbose=False)
+    q, p = rs.standard_normal((D, N)), rs.standard_normal((D, N))
+    w = hmc.ensembleWeights(q, p, temperature=2.0 / kB)
+    _, Hh = orc.weights(orc.pot_harmonic(np.array([2.0, 3.0, 0.5])), q, p, ens.mass)
+    e = np.exp(-(Hh - Hh.min()) / 2.0)
+    assert np.allclose(w, e / e.sum(), rtol=1e-12) and ens.weights is w and abs(w.sum() - 1) < 1e-12
+    # unnormalised weights are what getWeights returns (src/HMC.py:103)
+    assert np.allclose(hmc.getWeights(q, p), np.exp(-Hh), rtol=1e-12)
