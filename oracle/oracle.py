@@ -90,7 +90,10 @@ def pot_custom(source, D, params=()):
     HOST (g++ -O2 -ffp-contract=off, T = double, q / g plain pointers) and called chain by chain
     by the oracle's integrators -- the CPU side of the parity tests of CustomPotential."""
     import hashlib
-    tu = ('#include <cmath>\n#include <cstdint>\nusing namespace std;\nusing T = double;\n'
+    # `source` is the text that goes inside namespace user: the tests hand over
+    # custom.complete_source(user_source), the same text the device plugin is built from
+    tu = ('#include <cmath>\n#include <cstdint>\n#include <type_traits>\n#include <utility>\n'
+          'using namespace std;\nusing T = double;\n'
           '#define PBBI_FN static inline\nnamespace user {\n' + source + '\n}\n'
           'extern "C" double pbbi_user_U(const double* q, int D, const double* prm) '
           '{ return user::potential(q, D, prm); }\n'

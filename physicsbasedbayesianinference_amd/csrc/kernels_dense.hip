@@ -423,9 +423,8 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
 //      (~60 fp64 polynomial constants of log/sincospi/exp, all row offsets) and keeps them
 //      live for the whole kernel (~140 VGPRs); branches around array updates double the
 //      arrays through phi copies; flat addressing costs one 64-bit VGPR address per row.
-// The momentum draw is a ROLLED Philox/Box-Muller loop that writes the momentum slab, which
-// the lane then reads back exactly like an uploaded p_in (unrolled into registers the 16
-// inlined bodies spill hundreds of VGPRs).
+// The momentum is drawn straight into the velocity registers: one Philox block and two
+// single-precision Box-Muller transforms per four rows (pbbi_rng.h), nothing goes through memory.
 // ------------------------------------------------------------------------------------------
 constexpr int BLOCK2 = 512;
 constexpr int CHAINS_PER_WG2 = 128;

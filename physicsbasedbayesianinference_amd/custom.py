@@ -25,13 +25,28 @@ element j of ONE chain):
     }
 
 Use unqualified math calls (`exp`, `log`, `log1p`, `sqrt`, `tanh`, `fma`, ...): the same source is
-compiled for the host by the test oracle (oracle/oracle.py::pot_custom).  There is no autodiff:
-the gradient is the user's (check it with `CustomPotential.check_gradient`).  No CPU fallback:
-without hipcc or a GPU the constructor raises.
+compiled for the host by the test oracle (oracle/oracle.py::pot_custom).
+
+Automatic gradient (the reference's default, `grad(self.potential)`, src/HMC.py:57-60): a source
+WITHOUT a `gradient` function gets one by forward-mode differentiation -- `potential` is
+instantiated on dual numbers (csrc/pbbi_autodiff.h), one pass per coordinate.  Such a potential
+must be written on the element type of its view, `pbbi_scalar<Q>`, instead of `T`:
+
+    template <class Q>
+    PBBI_FN pbbi_scalar<Q> potential(const Q& q, int D, const T* prm) {
+        pbbi_scalar<Q> s = 0;
+        for (int j = 0; j < D; ++j) s += log1p(exp(-q[j])) + T(0.5) * prm[0] * q[j] * q[j];
+        return s;
+    }
+
+It costs D potential evaluations per gradient (a hand-written gradient stays the fast path and can
+be checked against it: `CustomPotential.check_gradient`, or build both and compare).  No CPU
+fallback: without hipcc or a GPU the constructor raises.
 """
 import ctypes as C
 import hashlib
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -39,7 +54,8 @@ import numpy as np
 from . import _lib
 from .potential import Potential, _dptr
 
-__all__ = ["CustomPotential", "compile_plugin", "plugin_source", "coin_toss_posterior",
+__all__ = ["CustomPotential", "compile_plugin", "plugin_source", "complete_source", "has_gradient",
+           "coin_toss_posterior",
            "logistic_regression_posterior", "COIN_TOSS_SOURCE", "LOGISTIC_REGRESSION_SOURCE",
            "EXAMPLE_SOURCE"]
 
@@ -50,12 +66,35 @@ _CACHE = os.path.join(_HERE, "_plugins")
 _DEPS = ("pbbi_custom.h", "pbbi_internal.h", "pbbi_rng.h")
 
 
+_AD_GRADIENT = """
+// no gradient in the source: forward-mode automatic differentiation (csrc/pbbi_autodiff.h)
+template <class Q, class G>
+PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
+    for (int k = 0; k < D; ++k) g[k] = potential(pbbi_ad::Seeded<Q>{q, k}, D, prm).d;
+}
+"""
+
+
+def has_gradient(source):
+    return re.search(r"\bvoid\s+gradient\s*\(", source) is not None
+
+
+def complete_source(source):
+    """What goes inside `namespace user` of a generated translation unit (device plugin and the test
+    oracle's host build alike): the dual-number support text, the user's source, and -- when the
+    source states no `gradient` -- the automatic one."""
+    with open(os.path.join(_CSRC, "pbbi_autodiff.h")) as f:
+        ad = f.read()
+    return ad + "\n" + source + ("" if has_gradient(source) else _AD_GRADIENT)
+
+
 def plugin_source(source, dtype="float64", D=None):
     """The translation unit hipcc sees for one user source (and one dimension: PBBI_D lets small
     chains run from registers, csrc/pbbi_custom.h)."""
+    source = complete_source(source)
     ctype = {"float64": "double", "float32": "float"}[str(np.dtype(dtype))]
     return ((f'#define PBBI_D {int(D)}\n' if D else '') +
-            '#include <hip/hip_runtime.h>\n#include <type_traits>\n'
+            '#include <hip/hip_runtime.h>\n#include <type_traits>\n#include <utility>\n'
             '#include "pbbi_internal.h"\n#include "pbbi_rng.h"\n'
             f'using T = {ctype};\n#define PBBI_FN __device__ __forceinline__\n'
             'namespace user {\n' + source + '\n}  // namespace user\n'
@@ -108,6 +147,7 @@ class CustomPotential(Potential):
     def __init__(self, D, source, params=(), dtype="float64", device=None, verbose=False):
         super().__init__(D, dtype, device)
         self.source = source
+        self.autodiff = not has_gradient(source)   # gradient by dual numbers (csrc/pbbi_autodiff.h)
         self.params = np.ascontiguousarray(params, dtype=np.float64).ravel()
         self.plugin_path = compile_plugin(source, self.dtype, verbose=verbose, D=int(D))
         _lib.call("pbbi_potential_create_custom", self.plugin_path.encode(), int(D),
@@ -148,20 +188,21 @@ PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
 
 # Coin toss: theta ~ Beta(a, b), k heads in n tosses, sampled in x = logit(theta) (unconstrained;
 # the Jacobian theta (1 - theta) is included):  U(x) = A softplus(-x) + B softplus(x),
-# A = k + a, B = n - k + b; prm = [A, B].  D independent coins share the constants.
+# A = k + a, B = n - k + b.  D independent coins, each with its own data: prm = [A_0, B_0, A_1, B_1, ...]
+# (the reference's example tosses TWO coins c1, c2 with biases p1, p2: samples/NumpyroExamples/CoinToss).
 COIN_TOSS_SOURCE = """
 PBBI_FN T softplus(T z) { return (z > 0 ? z : T(0)) + log1p(exp(-fabs(z))); }
 template <class Q>
 PBBI_FN T potential(const Q& q, int D, const T* prm) {
     T s = 0;
-    for (int j = 0; j < D; ++j) s += prm[0] * softplus(-q[j]) + prm[1] * softplus(q[j]);
+    for (int j = 0; j < D; ++j) s += prm[2 * j] * softplus(-q[j]) + prm[2 * j + 1] * softplus(q[j]);
     return s;
 }
 template <class Q, class G>
 PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
     for (int j = 0; j < D; ++j) {
         const T sig = T(1) / (T(1) + exp(-q[j]));
-        g[j] = prm[1] * sig - prm[0] * (T(1) - sig);
+        g[j] = prm[2 * j + 1] * sig - prm[2 * j] * (T(1) - sig);
     }
 }
 """
@@ -202,10 +243,20 @@ PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {
 """
 
 
-def coin_toss_posterior(heads, tosses, a=1.0, b=1.0, D=1, **kw):
-    """Posterior of a coin's bias theta ~ Beta(a, b) after `heads` in `tosses`, as a potential in
-    x = logit(theta); theta = 1/(1+exp(-x)) of the samples is Beta(heads+a, tosses-heads+b)."""
-    return CustomPotential(D, COIN_TOSS_SOURCE, [heads + a, tosses - heads + b], **kw)
+def coin_toss_posterior(heads, tosses, a=1.0, b=1.0, D=None, **kw):
+    """Posterior of the biases theta_j ~ Beta(a, b) of independent coins after heads[j] in tosses[j],
+    as a potential in x = logit(theta); theta_j = 1/(1+exp(-x_j)) of the samples is
+    Beta(heads[j]+a, tosses[j]-heads[j]+b).  `heads` / `tosses` / `a` / `b` are scalars or one value per
+    coin -- the reference's example (samples/NumpyroExamples/CoinToss/CoinToss.py:18-22) is
+    coin_toss_posterior([k1, k2], [n1, n2]) with its uniform prior a = b = 1; D (default: the number of
+    entries) repeats scalar data over D coins."""
+    k, n, a, b = (np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in (heads, tosses, a, b))
+    D = int(max(k.size, n.size, a.size, b.size) if D is None else D)
+    k, n, a, b = (np.broadcast_to(x, (D,)) for x in (k, n, a, b))
+    if np.any(k > n) or np.any(k < 0):
+        raise ValueError("need 0 <= heads <= tosses for every coin")
+    prm = np.stack([k + a, n - k + b], axis=1).ravel()
+    return CustomPotential(D, COIN_TOSS_SOURCE, prm, **kw)
 
 
 def logistic_regression_params(X, y, prior_precision=1.0):

@@ -43,3 +43,46 @@ def logistic_numpy(X, y, lam, q):
     U = np.sum(np.logaddexp(0.0, z) - y[:, None] * z, axis=0) + 0.5 * lam * np.sum(q * q, axis=0)
     g = X.T @ (1.0 / (1.0 + np.exp(-z)) - y[:, None]) + lam * q
     return U, g
+
+
+# ---- potentials WITHOUT a gradient function: the product differentiates them by dual numbers
+# (custom.py, csrc/pbbi_autodiff.h).  Same functions as above, written on pbbi_scalar<Q>.
+QUARTIC_AD = '''
+template <class Q>
+PBBI_FN pbbi_scalar<Q> potential(const Q& q, int D, const T* prm) {
+    pbbi_scalar<Q> s = 0, c = 0;
+    for (int j = 0; j < D; ++j) s += ((q[j] * q[j]) * (q[j] * q[j]));
+    for (int j = 0; j + 1 < D; ++j) { const pbbi_scalar<Q> d = q[j] - q[j + 1]; c += d * d; }
+    return (T(0.25) * prm[0]) * s + (T(0.5) * prm[1]) * c;
+}
+'''
+
+LOGISTIC_AD = '''
+template <class S> PBBI_FN S softplus(S z) { return (z > 0 ? z : S(0)) + log1p(exp(-fabs(z))); }
+template <class Q>
+PBBI_FN pbbi_scalar<Q> potential(const Q& q, int D, const T* prm) {
+    const int M = (int)prm[0];
+    const T* X = prm + 1;
+    const T* y = X + (long)M * D;
+    const T lam = y[M];
+    pbbi_scalar<Q> s = 0, r = 0;
+    for (int i = 0; i < M; ++i) {
+        pbbi_scalar<Q> z = 0;
+        for (int j = 0; j < D; ++j) z += X[i * D + j] * q[j];
+        s += softplus(z) - y[i] * z;
+    }
+    for (int j = 0; j < D; ++j) r += q[j] * q[j];
+    return s + (T(0.5) * lam) * r;
+}
+'''
+
+# the reference's coin toss (samples/NumpyroExamples/CoinToss) in logit space, no gradient given
+COIN_TOSS_AD = '''
+template <class S> PBBI_FN S softplus(S z) { return (z > 0 ? z : S(0)) + log1p(exp(-fabs(z))); }
+template <class Q>
+PBBI_FN pbbi_scalar<Q> potential(const Q& q, int D, const T* prm) {
+    pbbi_scalar<Q> s = 0;
+    for (int j = 0; j < D; ++j) s += prm[2 * j] * softplus(-q[j]) + prm[2 * j + 1] * softplus(q[j]);
+    return s;
+}
+'''

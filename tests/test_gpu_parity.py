@@ -951,6 +951,20 @@ def test_coin_toss_posterior(P):
     assert abs(theta.mean() - A / (A + B)) < 3e-3
     assert abs(theta.var() / (A * B / ((A + B) ** 2 * (A + B + 1))) - 1.0) < 0.05
     assert hmc.acceptRate > 0.95
+    # the reference's example: TWO coins with their own tosses and a uniform prior
+    # (samples/NumpyroExamples/CoinToss/CoinToss.py:18-22): theta_j ~ Beta(k_j + 1, n_j - k_j + 1)
+    k, n = np.array([62.0, 11.0]), np.array([100.0, 40.0])
+    pot2 = coin_toss_posterior(k, n)
+    assert pot2.numDimensions == 2
+    hmc = P.HMC(P.Ensemble(2, 8192), 1.0, 0.1, None, potential=pot2, rng="philox", seed=3, verbose=False)
+    s, _ = hmc.getSamples(40, 1.0 / kB, 1.0, jitter=0.5)   # omega*T is near pi for coin 2 at T = 1
+    theta = 1.0 / (1.0 + np.exp(-s[:, :, 10:]))
+    for j in range(2):
+        A, B = k[j] + 1, n[j] - k[j] + 1
+        assert abs(theta[j].mean() - A / (A + B)) < 3e-3
+        assert abs(theta[j].var() / (A * B / ((A + B) ** 2 * (A + B + 1))) - 1.0) < 0.06
+    with pytest.raises(ValueError):
+        coin_toss_posterior([5], [3])
 
 
 def test_dual_averaging_step_size(P):
@@ -1000,8 +1014,8 @@ def test_warmup_draws_are_disjoint_from_sampling_draws(P, lib):
 @pytest.mark.parametrize("D,N,mass,compat", [(32, 2500, False, True), (32, 333, True, False),
                                              (23, 1000, False, True)])
 def test_rosenbrock_run_with_many_rejections_bitexact(P, lib, D, N, mass, compat):
-    """pbbi_hmc_run on the two-lane kernel (chains partitioned over internal streams when the
-    ensemble is large) with a step large enough for frequent rejections: replayed by the oracle
+    """pbbi_hmc_run on the two-lane kernel (several iterations fused into one launch, the chain in
+    registers in between) with a step large enough for frequent rejections: replayed by the oracle
     from the device draws, and by per-iteration pbbi_hmc_iter calls with the same draws --
     bit-exact, including chains rejected after earlier rejections."""
     S, L, h, seed, chain0, iter0 = 6, 10, 0.05, 77, 12345, 3
@@ -1582,3 +1596,57 @@ def test_ensemble_weights_on_device(P, lib):
     assert np.allclose(w, e / e.sum(), rtol=1e-12) and ens.weights is w and abs(w.sum() - 1) < 1e-12
     # unnormalised weights are what getWeights returns (src/HMC.py:103)
     assert np.allclose(hmc.getWeights(q, p), np.exp(-Hh), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ automatic gradient
+@pytest.mark.parametrize("name,D,rtol", [("quartic", 11, 1e-12), ("quartic", 40, 1e-12), ("logistic", 5, 1e-10),
+                                         ("coin", 2, 1e-10)])
+def test_autodiff_gradient_matches_handwritten(P, lib, name, D, rtol):
+    """A source WITHOUT `gradient` (the reference's default path, jax.grad(potential), src/HMC.py:57-60)
+    is differentiated by dual numbers inside the kernels (csrc/pbbi_autodiff.h): its gradient equals the
+    hand-written one (1e-12 on polynomials), on the register-resident (D <= 16) and the workspace
+    kernels, and sampling with it reproduces sampling with the hand-written gradient."""
+    from custom_sources import (COIN_TOSS_AD, COIN_TOSS_SOURCE, LOGISTIC, LOGISTIC_AD, QUARTIC, QUARTIC_AD,
+                                logistic_problem)
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    rs = np.random.RandomState(D)
+    if name == "quartic":
+        hand, auto, prm = QUARTIC, QUARTIC_AD, [1.5, 0.5]
+    elif name == "logistic":
+        hand, auto = LOGISTIC, LOGISTIC_AD
+        prm = logistic_problem(M=40, D=D)[3]
+    else:
+        hand, auto, prm = COIN_TOSS_SOURCE, COIN_TOSS_AD, [63.0, 39.0, 12.0, 30.0]
+    ph, pa = CustomPotential(D, hand, prm), CustomPotential(D, auto, prm)
+    assert pa.autodiff and not ph.autodiff
+    q = rs.standard_normal((D, 300))
+    Uh, gh = ph.value_and_gradient(q)
+    Ua, ga = pa.value_and_gradient(q)
+    assert np.allclose(Ua, Uh, rtol=1e-13, atol=1e-13)
+    assert np.max(np.abs(ga - gh)) <= rtol * max(1.0, np.max(np.abs(gh)))
+    assert pa.check_gradient(q[:, :8]) < 1e-6            # and both agree with central differences
+    # one HMC run each: same draws, same decisions, states within the gradient's rounding
+    out = []
+    for pot in (ph, pa):
+        hmc = P.HMC(P.Ensemble(D, 256), 0.5, 0.05, None, potential=pot, rng="philox", seed=4, verbose=False,
+                    kdk_fma=False)
+        s, m = hmc.getSamples(3, 1.0 / kB, 0.5)
+        out.append((s, m, hmc.reject_masks.copy()))
+    assert np.array_equal(out[0][2], out[1][2])
+    assert scaled_err(out[1][0], out[0][0]) <= 1e-10 and scaled_err(out[1][1], out[0][1]) <= 1e-10
+
+
+def test_coin_toss_sampled_without_a_gradient(P):
+    """The reference's two-coin example end to end with potential only (its NumPyro model gives
+    log_density and jax.grad gives the gradient, CoinTossExample.py:75-107): Beta posteriors recovered."""
+    from custom_sources import COIN_TOSS_AD
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    k, n = np.array([62.0, 11.0]), np.array([100.0, 40.0])
+    pot = CustomPotential(2, COIN_TOSS_AD, np.stack([k + 1, n - k + 1], axis=1).ravel())
+    hmc = P.HMC(P.Ensemble(2, 8192), 1.0, 0.1, None, potential=pot, rng="philox", seed=3, verbose=False)
+    s, _ = hmc.getSamples(40, 1.0 / kB, 1.0, jitter=0.5)   # omega*T is near pi for coin 2 at T = 1
+    theta = 1.0 / (1.0 + np.exp(-s[:, :, 10:]))
+    for j in range(2):
+        A, B = k[j] + 1, n[j] - k[j] + 1
+        assert abs(theta[j].mean() - A / (A + B)) < 3e-3
+        assert abs(theta[j].var() / (A * B / ((A + B) ** 2 * (A + B + 1))) - 1.0) < 0.06

@@ -207,13 +207,16 @@ def test_custom_potential_plugin_builds_and_exports():
     the plugins of the GPU parity tests in the in-tree cache, which travels to the GPU box)."""
     import subprocess
     from physicsbasedbayesianinference_amd.custom import compile_plugin
-    from custom_sources import COIN_TOSS_SOURCE, LOGISTIC, QUARTIC
+    from custom_sources import COIN_TOSS_AD, COIN_TOSS_SOURCE, LOGISTIC, LOGISTIC_AD, QUARTIC, QUARTIC_AD
     # (source, dtype, D): the dimensions the GPU parity tests construct (D <= 16 in fp64 / 32 in fp32
     # compile the register-resident kernels as well), and one build without a fixed dimension
     for src, dtype, D in ((QUARTIC, "float64", 11), (QUARTIC, "float64", 40), (LOGISTIC, "float64", 5),
                           (QUARTIC, "float32", 7), (COIN_TOSS_SOURCE, "float64", 1),
                           (QUARTIC, "float64", 9), (QUARTIC, "float64", 20), (QUARTIC, "float64", 24),
-                          (QUARTIC, "float64", 12),
+                          (QUARTIC, "float64", 12), (COIN_TOSS_SOURCE, "float64", 2),
+                          # sources without a gradient: dual-number autodiff (csrc/pbbi_autodiff.h)
+                          (QUARTIC_AD, "float64", 11), (QUARTIC_AD, "float64", 40), (LOGISTIC_AD, "float64", 5),
+                          (COIN_TOSS_AD, "float64", 2), (QUARTIC_AD, "float32", 7),
                           (QUARTIC, "float64", None)):
         so = compile_plugin(src, dtype, D=D)
         syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
@@ -223,6 +226,25 @@ def test_custom_potential_plugin_builds_and_exports():
         assert compile_plugin(src, dtype, D=D) == so  # cache hit
     with pytest.raises(RuntimeError, match="hipcc failed"):
         compile_plugin("this is not C++")
+
+
+def test_autodiff_source_on_the_host():
+    """The dual-number text (csrc/pbbi_autodiff.h) compiled for the HOST by the oracle's g++ build:
+    the automatic gradient of the gradient-less sources equals the hand-written ones."""
+    from oracle import oracle as orc
+    from physicsbasedbayesianinference_amd.custom import complete_source, has_gradient
+    from custom_sources import LOGISTIC, LOGISTIC_AD, QUARTIC, QUARTIC_AD, logistic_problem
+    assert has_gradient(QUARTIC) and not has_gradient(QUARTIC_AD)
+    rs = np.random.RandomState(1)
+    q = rs.standard_normal((6, 9))
+    U0, g0 = orc.potential(orc.pot_custom(complete_source(QUARTIC), 6, [2.0, 0.5]), q, want_grad=True)
+    U1, g1 = orc.potential(orc.pot_custom(complete_source(QUARTIC_AD), 6, [2.0, 0.5]), q, want_grad=True)
+    assert np.array_equal(U0, U1) and np.allclose(g0, g1, rtol=1e-13, atol=1e-14)
+    X, y, lam, prm = logistic_problem()
+    q = rs.standard_normal((X.shape[1], 7))
+    U0, g0 = orc.potential(orc.pot_custom(complete_source(LOGISTIC), X.shape[1], prm), q, want_grad=True)
+    U1, g1 = orc.potential(orc.pot_custom(complete_source(LOGISTIC_AD), X.shape[1], prm), q, want_grad=True)
+    assert np.allclose(U0, U1, rtol=1e-13) and np.allclose(g0, g1, rtol=1e-11, atol=1e-12)
 
 
 def test_oracle_custom_potential_matches_numpy():
