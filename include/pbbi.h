@@ -241,6 +241,22 @@ int pbbi_sample_moments(const void* samples_sdn, int S, int D, int64_t N, int dt
 int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
                        void* chain_mean_out, void* chain_var_out, void* stream);
 
+/* Ensemble-averaged autocovariance of the chains' draws at lags 0..T (T <= PBBI_MAX_LAG):
+ *   acov_out[t*D + d] = mean_n (1/S) sum_{s < S-t} (x[s,d,n] - m[d,n]) (x[s+t,d,n] - m[d,n]),
+ * m = chain_mean (D, N) from pbbi_chain_moments.  acov_out: (T+1, D) DOUBLES on the device (fp64
+ * accumulation, deterministic two-stage reduction over the chains).  The ingredient of the effective
+ * sample size of the ensemble (HMC.ess in the Python layer). */
+#define PBBI_MAX_LAG 32
+int pbbi_chain_autocov(const void* samples_sdn, const void* chain_mean, int S, int D, int64_t N, int T,
+                       int dtype, int device, double* acov_out, void* stream);
+
+/* Covariance matrix of all S*N draws: cov_out[i*D + j] = mean((x_i - mean_i)(x_j - mean_j)), D x D
+ * DOUBLES on the device, row-major, symmetric; `mean` (D doubles on the device) is subtracted before
+ * the products (give the output of pbbi_sample_moments converted to double, or any shift: the result
+ * is then the second moment about that point). */
+int pbbi_sample_covariance(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                           const double* mean, double* cov_out, void* stream);
+
 /* ---- ensemble weights ----------------------------------------------
  * Normalised canonical weights of an ensemble from its per-chain Hamiltonians (pbbi_energy),
  *     w_n = exp(-beta (H_n - H_min)) / sum_m exp(-beta (H_m - H_min)),

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "pbbi_transpose_sdn_to_dns": [_vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "pbbi_sample_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
     "pbbi_chain_moments": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
+    "pbbi_chain_autocov": [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp],
+    "pbbi_sample_covariance": [_vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp],
     "pbbi_reduce_min": [_vp, _i64, _i, _i, _vp, _vp],
     "pbbi_canonical_weights": [_vp, _i64, _d, _vp, _i, _i, _vp, _vp, _vp],
     "pbbi_scale_inverse": [_vp, _i64, _vp, _i, _i, _vp],

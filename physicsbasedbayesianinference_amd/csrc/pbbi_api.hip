@@ -261,6 +261,100 @@ __global__ void k_chain_moments(const T* __restrict__ x, int S, int D, int64_t N
     if (var_out) var_out[(int64_t)d * N + n] = (T)(m2 / (double)(S - 1));
 }
 
+// lagged products of one (dim, chain) series through a register window: acc[t] += x_s * x_{s-t}
+template <typename T>
+__global__ void __launch_bounds__(256) k_chain_autocov(const T* __restrict__ x, const T* __restrict__ mean,
+                                                       int S, int D, int64_t N, double* __restrict__ part) {
+    constexpr int TL = PBBI_MAX_LAG + 1;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    double acc[TL], w[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) { acc[t] = 0.0; w[t] = 0.0; }
+    if (n < N) {
+        const double m = (double)mean[(int64_t)d * N + n];
+        for (int s = 0; s < S; ++s) {
+            const double v = (double)x[((int64_t)s * D + d) * N + n] - m;
+#pragma unroll
+            for (int t = TL - 1; t > 0; --t) w[t] = w[t - 1];
+            w[0] = v;
+#pragma unroll
+            for (int t = 0; t < TL; ++t) acc[t] = fma(v, w[t], acc[t]);
+        }
+    }
+    // sum over the block's chains, lag by lag (fixed order: deterministic)
+    __shared__ double r[256];
+    for (int t = 0; t < TL; ++t) {
+        r[threadIdx.x] = acc[t];
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) r[threadIdx.x] += r[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[((size_t)blockIdx.x * D + d) * TL + t] = r[0];
+        __syncthreads();
+    }
+}
+
+__global__ void k_autocov_final(const double* __restrict__ part, int n_blocks, int D, int T, double scale,
+                                double* __restrict__ out) {
+    constexpr int TL = PBBI_MAX_LAG + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // t*D + d
+    if (i >= (T + 1) * D) return;
+    const int t = i / D, d = i - t * D;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += part[((size_t)b * D + d) * TL + t];
+    out[i] = s * scale;
+}
+
+// one 16x16 tile of sum_m (x_i - mean_i)(x_j - mean_j) over a chunk of the S*N draws (tiles on and above
+// the diagonal only); partial tiles are summed in a fixed order by k_cov_final
+template <typename T>
+__global__ void __launch_bounds__(256) k_cov_partial(const T* __restrict__ x, const double* __restrict__ mean,
+                                                     int S, int D, int64_t N, int chunks,
+                                                     double* __restrict__ part /* [chunks][D][D] */) {
+    const int ti = blockIdx.y, tj = blockIdx.z;
+    if (tj < ti) return;
+    const int li = threadIdx.x >> 4, lj = threadIdx.x & 15;
+    const int64_t M = (int64_t)S * N;
+    const int64_t per = ((M + chunks - 1) / chunks + 63) / 64 * 64;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
+    __shared__ double xi[16][65], xj[16][65];
+    double acc = 0.0;
+    for (int64_t m0 = lo; m0 < hi; m0 += 64) {
+        for (int k = threadIdx.x; k < 16 * 64; k += 256) {  // rows of the two tiles, 64 draws each
+            const int row = k >> 6, c = k & 63;
+            const int64_t m = m0 + c;
+            double a = 0.0, b = 0.0;
+            if (m < hi) {
+                const int64_t s = m / N, n = m - s * N;
+                const int di = ti * 16 + row, dj = tj * 16 + row;
+                if (di < D) a = (double)x[(s * D + di) * N + n] - mean[di];
+                if (dj < D) b = (double)x[(s * D + dj) * N + n] - mean[dj];
+            }
+            xi[row][c] = a;
+            xj[row][c] = b;
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int c = 0; c < 64; ++c) acc = fma(xi[li][c], xj[lj][c], acc);
+        __syncthreads();
+    }
+    const int i = ti * 16 + li, j = tj * 16 + lj;
+    if (i < D && j < D) part[((size_t)blockIdx.x * D + i) * D + j] = acc;
+}
+
+__global__ void k_cov_final(const double* __restrict__ part, int chunks, int D, double inv_count,
+                            double* __restrict__ cov) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= D * D) return;
+    int i = idx / D, j = idx - i * D;
+    if ((j >> 4) < (i >> 4)) { const int t = i; i = j; j = t; }  // below-diagonal tiles mirror the upper ones
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += part[((size_t)c * D + i) * D + j];
+    cov[idx] = s * inv_count;
+}
+
 // ensemble weights: stage 1 of a deterministic two-stage reduction (MODE 0: min of x, NaNs skipped;
 // MODE 1: w = exp(-beta (H - hmin)) stored, partial sums of w)
 template <typename T, int MODE>
@@ -739,6 +833,60 @@ int pbbi_chain_moments(const void* samples_sdn, int S, int D, int64_t N, int dty
                            (const float*)samples_sdn, S, D, N, (float*)chain_mean_out,
                            (float*)chain_var_out);
     PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int pbbi_chain_autocov(const void* samples_sdn, const void* chain_mean, int S, int D, int64_t N, int T,
+                       int dtype, int device, double* acov_out, void* stream) {
+    if (S < 2 || D < 1 || N < 1) return pbbi_fail(PBBI_ERR_INVALID, "need S >= 2, D >= 1, N >= 1");
+    if (T < 0 || T > PBBI_MAX_LAG) return pbbi_fail(PBBI_ERR_INVALID, "T must be in [0, PBBI_MAX_LAG]");
+    if (!samples_sdn || !chain_mean || !acov_out) return pbbi_fail(PBBI_ERR_INVALID, "a pointer is NULL");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    DeviceGuard guard(device);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_blocks = (int)((N + 255) / 256);
+    double* part = nullptr;
+    PBBI_HIP(hipMallocAsync((void**)&part, sizeof(double) * (size_t)n_blocks * D * (PBBI_MAX_LAG + 1), st));
+    const dim3 grid((unsigned)n_blocks, (unsigned)D), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_chain_autocov<double>, grid, block, 0, st, (const double*)samples_sdn,
+                           (const double*)chain_mean, S, D, N, part);
+    else
+        hipLaunchKernelGGL(k_chain_autocov<float>, grid, block, 0, st, (const float*)samples_sdn,
+                           (const float*)chain_mean, S, D, N, part);
+    const int outs = (T + 1) * D;
+    hipLaunchKernelGGL(k_autocov_final, dim3((outs + 255) / 256), dim3(256), 0, st, (const double*)part,
+                       n_blocks, D, T, 1.0 / ((double)S * (double)N), acov_out);
+    PBBI_HIP(hipGetLastError());
+    PBBI_HIP(hipFreeAsync(part, st));
+    return PBBI_OK;
+}
+
+int pbbi_sample_covariance(const void* samples_sdn, int S, int D, int64_t N, int dtype, int device,
+                           const double* mean, double* cov_out, void* stream) {
+    if (S < 1 || D < 1 || N < 1) return pbbi_fail(PBBI_ERR_INVALID, "S, D, N must be >= 1");
+    if (!samples_sdn || !mean || !cov_out) return pbbi_fail(PBBI_ERR_INVALID, "a pointer is NULL");
+    if (dtype != PBBI_F64 && dtype != PBBI_F32) return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    DeviceGuard guard(device);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = (D + 15) / 16;
+    const int64_t M = (int64_t)S * N;
+    int chunks = (int)(M / 4096 > 0 ? M / 4096 : 1);
+    const int max_chunks = tiles * tiles >= 64 ? 64 : 1024 / (tiles * tiles);
+    if (chunks > max_chunks) chunks = max_chunks;
+    double* part = nullptr;
+    PBBI_HIP(hipMallocAsync((void**)&part, sizeof(double) * (size_t)chunks * D * D, st));
+    const dim3 grid((unsigned)chunks, (unsigned)tiles, (unsigned)tiles), block(256);
+    if (dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_cov_partial<double>, grid, block, 0, st, (const double*)samples_sdn, mean, S, D,
+                           N, chunks, part);
+    else
+        hipLaunchKernelGGL(k_cov_partial<float>, grid, block, 0, st, (const float*)samples_sdn, mean, S, D, N,
+                           chunks, part);
+    hipLaunchKernelGGL(k_cov_final, dim3((D * D + 255) / 256), dim3(256), 0, st, (const double*)part, chunks,
+                       D, 1.0 / (double)M, cov_out);
+    PBBI_HIP(hipGetLastError());
+    PBBI_HIP(hipFreeAsync(part, st));
     return PBBI_OK;
 }
 

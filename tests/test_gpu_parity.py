@@ -1650,3 +1650,48 @@ def test_coin_toss_sampled_without_a_gradient(P):
         A, B = k[j] + 1, n[j] - k[j] + 1
         assert abs(theta[j].mean() - A / (A + B)) < 3e-3
         assert abs(theta[j].var() / (A * B / ((A + B) ** 2 * (A + B + 1))) - 1.0) < 0.06
+
+
+# ------------------------------------------------------------------ covariance and ESS in the sink
+def test_sample_covariance_and_ess_match_numpy(P, lib):
+    """pbbi_sample_covariance and pbbi_chain_autocov / HMC.ess against NumPy on AR(1) chains with known
+    autocorrelation phi: ESS ~ N*S*(1-phi)/(1+phi); D not a multiple of 16, fp32 slabs too."""
+    import torch
+    rs = np.random.RandomState(0)
+    D, N, S = 19, 700, 120
+    phi = np.linspace(-0.3, 0.8, D)
+    x = np.empty((S, D, N))
+    x[0] = rs.standard_normal((D, N))
+    for s in range(1, S):
+        x[s] = phi[:, None] * x[s - 1] + np.sqrt(1 - phi[:, None] ** 2) * rs.standard_normal((D, N))
+    x[:, 3] += 0.7 * x[:, 5]                                  # some cross-covariance
+    x += 5.0 * np.arange(D)[None, :, None]                    # large means: the shift matters
+    hmc = P.HMC(P.Ensemble(D, N), 1.0, 0.1, None, potential=P.StandardGaussian(D), verbose=False)
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        xd = torch.tensor(x, dtype=dtype, device="cuda")
+        dns = xd.permute(1, 2, 0)
+        mean, cov = hmc.sampleCovariance(dns)
+        flat = xd.double().cpu().numpy().transpose(1, 0, 2).reshape(D, -1)
+        assert np.allclose(mean, flat.mean(1), rtol=1e-6 if dtype == torch.float32 else 1e-12)
+        ref = np.cov(flat, bias=True) if dtype == torch.float64 else np.cov(flat - mean[:, None] + flat.mean(1)[:, None], bias=True)
+        assert np.max(np.abs(cov - np.cov(flat, bias=True))) < tol * max(1.0, np.max(np.abs(ref))) + (2e-4 if dtype == torch.float32 else 0)
+        assert np.array_equal(cov, cov.T)
+    # autocovariance kernel against NumPy, lag by lag
+    xd = torch.tensor(x, dtype=torch.float64, device="cuda")
+    from physicsbasedbayesianinference_amd._device import stream_ptr
+    cm = xd.mean(0).contiguous()
+    T = 20
+    acov = torch.empty((T + 1, D), dtype=torch.float64, device="cuda")
+    lib.call("pbbi_chain_autocov", xd.data_ptr(), cm.data_ptr(), S, D, N, T, lib.F64, 0, acov.data_ptr(), stream_ptr(0))
+    torch.cuda.synchronize()
+    xc = x - x.mean(0, keepdims=True)
+    for t in (0, 1, 7, T):
+        ref = (xc[:S - t] * xc[t:]).sum(0).mean(1) / S
+        assert np.allclose(acov[t].cpu().numpy(), ref, rtol=1e-11, atol=1e-13)
+    ess = hmc.ess(xd.permute(1, 2, 0))
+    expect = N * S * (1 - phi) / (1 + phi)
+    ok = np.ones(D, dtype=bool)
+    ok[3] = False                                             # the mixed dimension has another spectrum
+    assert np.all(np.abs(ess[ok] / expect[ok] - 1.0) < 0.15), ess / expect
+    with pytest.raises(lib.PbbiError):
+        lib.call("pbbi_chain_autocov", xd.data_ptr(), cm.data_ptr(), S, D, N, 33, lib.F64, 0, acov.data_ptr(), stream_ptr(0))
