@@ -43,6 +43,12 @@
 
 namespace {
 
+#ifdef PBBI_DRAW_F64
+typedef double draw_t;  // diagnostic build: the cost of a double-precision draw (pbbi_rng.h)
+#else
+typedef float draw_t;
+#endif
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
             const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
 #pragma unroll
             for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g
-                float z[4];
+                draw_t z[4];
                 rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)
@@ -561,7 +567,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
 #pragma unroll
         for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g, slot = 0..3
-            float z[4];
+            draw_t z[4];
             rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl)

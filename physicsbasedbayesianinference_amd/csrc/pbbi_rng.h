@@ -59,6 +59,29 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& zc
     zs = r * __builtin_amdgcn_sinf(u2);
 }
 
+#ifdef PBBI_DRAW_F64
+// DIAGNOSTIC build only (tools/build_variant.sh draw64 kernels_dense -- -DPBBI_DRAW_F64): what a
+// double-precision draw would cost -- 53-bit uniforms (two Philox blocks per four normals) through
+// the fp64 library log / sqrt / sincospi.  Not part of the RNG contract, not mirrored by the oracle:
+// only its THROUGHPUT is read.
+__device__ __forceinline__ void box_muller_f64(const PhiloxOut& x, double& zc, double& zs) {
+    const double u1 = ((double)((((uint64_t)x.x1 << 32) | x.x0) >> 11) + 0.5) * 0x1.0p-53;
+    const double u2 = (double)((((uint64_t)x.x3 << 32) | x.x2) >> 11) * 0x1.0p-53;
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    zc = r * cs;
+    zs = r * sn;
+}
+template <typename Z>
+__device__ __forceinline__ void rng_normal4(uint64_t seed, uint32_t stream, uint64_t iter,
+                                            uint64_t chain, uint32_t blk, Z (&z)[4]) {
+    double a, b, c, d;
+    box_muller_f64(rng_block(seed, stream, iter, chain, blk), a, b);
+    box_muller_f64(rng_block(seed, stream, iter, chain, blk | 0x80000000u), c, d);
+    z[0] = (Z)a; z[1] = (Z)b; z[2] = (Z)c; z[3] = (Z)d;
+}
+#else
 // The four standard normals of one block: z[slot], slot = (dim >> 2) & 3 of the dims
 // {16*(blk>>2) + (blk&3) + 4*slot}.
 __device__ __forceinline__ void rng_normal4(uint64_t seed, uint32_t stream, uint64_t iter,
@@ -67,6 +90,7 @@ __device__ __forceinline__ void rng_normal4(uint64_t seed, uint32_t stream, uint
     box_muller_f32(x.x0, x.x1, z[0], z[1]);
     box_muller_f32(x.x2, x.x3, z[2], z[3]);
 }
+#endif
 
 __device__ __forceinline__ uint32_t rng_block_of_dim(int dim) {
     return (uint32_t)(((dim >> 4) << 2) | (dim & 3));
