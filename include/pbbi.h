@@ -82,9 +82,21 @@ enum {
      * kB*T; the two agree only for T = 1/kB).  With the flag the chains sample exp(-U(q)/kT): the
      * canonical ensemble at that temperature.  kT is pbbi_hmc_run's argument; uploaded-draw iterations
      * state it through pbbi_hmc_iter_kt.  Without the flag (default) the reference's test is kept. */
-    PBBI_BETA_ACCEPT = 4
+    PBBI_BETA_ACCEPT = 4,
+    /* Per-chain trajectory lengths (pbbi_hmc_iter_dyn / pbbi_hmc_run_dyn; SURVEY 8f row 2 -- planned in
+     * the reference's WeekPlan.md:16-17, not a reference feature).  PBBI_PER_CHAIN_STEPS: chain n takes
+     * its OWN number of leapfrog steps L_n in [1, L] -- steps_in[n] (uploaded draws) or
+     * 1 + floor(u * L) with u from PBBI_STREAM_STEPS (in-kernel draws); lengths drawn independently of
+     * the state keep the HMC kernel valid, and a fixed length's resonances go away chain by chain.
+     * PBBI_UTURN_STOP: a chain stops after the first step j at which (q_j - q_0) . p_j < 0 (the
+     * no-U-turn criterion), at most L (or L_n) steps; steps_out[n] records where.  Stopping at the
+     * U-turn alone is NOT a reversible kernel: the flag is for measuring trajectory lengths during
+     * warm-up (HMC.adaptTrajectoryLength), not for the recorded run.  Lanes of finished chains are
+     * masked out; a wave leaves the loop when its last chain has. */
+    PBBI_PER_CHAIN_STEPS = 8,
+    PBBI_UTURN_STOP = 16
 };
-enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2 };
+enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2, PBBI_STREAM_STEPS = 3 };
 
 typedef struct pbbi_potential pbbi_potential; /* opaque */
 
@@ -210,6 +222,21 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
                  int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
                  uint64_t iter0, uint64_t chain0, double kT, void* stream);
 
+/* pbbi_hmc_iter_kt / pbbi_hmc_run with per-chain trajectory lengths (flags PBBI_PER_CHAIN_STEPS,
+ * PBBI_UTURN_STOP above).  steps_in (N int32, device; iter only): the chains' step counts, each in
+ * [0, L]; NULL = L for every chain.  steps_out (N, or (S, N) for run; may be NULL): the steps each
+ * chain took.  Leapfrog only.  Served by the chain-per-lane kernels (harmonic, diagonal Gaussian,
+ * Rosenbrock: fp64, D <= 32, bit-exact with the oracle) and, for PBBI_PER_CHAIN_STEPS, by the dense
+ * MFMA kernel (D <= 128); other paths return PBBI_ERR_UNSUPPORTED. */
+int pbbi_hmc_iter_dyn(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                      const void* u_in, const void* mass, const int32_t* steps_in, void* q_out, void* p_out,
+                      void* ratio_out, uint8_t* reject_out, int32_t* steps_out, int64_t N, int64_t ldn,
+                      double h, int L, int flags, double kT, void* stream);
+int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const void* mass,
+                     void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
+                     int32_t* steps_out, int64_t N, int64_t ldn, double h, int L, int S, int flags,
+                     uint64_t seed, uint64_t iter0, uint64_t chain0, double kT, void* stream);
+
 /* ---- RNG (device Philox stream) -------------------------------------------
  * out[d*ldn+n] = scale * z(dim d, chain chain0+n); scale_per_chain (N) overrides
  * scale when non-NULL.  Device-mode counterpart of Ensemble.setPosition /
@@ -219,6 +246,10 @@ int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t ch
                        int dtype, int device, void* out, void* stream);
 int pbbi_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int dtype,
                         int device, void* out, void* stream);
+/* out[n] = 1 + floor(u * L) capped at L, u = the PBBI_STREAM_STEPS uniform of chain chain0+n (block
+ * 0xFFFFFFFF, same 53-bit construction as the Metropolis uniform): what PBBI_PER_CHAIN_STEPS draws. */
+int pbbi_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int L, int device,
+                      int32_t* out, void* stream);
 
 /* ---- layout helper --------------------------------------------------------
  * (S, D, N) device slabs -> the reference's (D, N, S) S-fastest array

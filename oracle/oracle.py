@@ -210,6 +210,31 @@ def weights_ratio(pot, newQ, newP, oldQ, oldP, mass=None):
     return r
 
 
+def hmc_iter_dyn(pot, q, p, u, mass, h, L, steps_in=None, uturn=False, compat=COMPAT_P_FROM_OLDQ, beta=1.0):
+    """hmc_iter (Leapfrog) with per-chain trajectory lengths: steps_in (N int32, None = L for every
+    chain) and / or stop at the first U-turn.  Returns (ratio, reject_mask, steps_taken)."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert _dn(p) == (Dq, N) and Dq == D
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    m = _mass(mass, N)
+    si = None if steps_in is None else np.ascontiguousarray(steps_in, dtype=np.int32)
+    ratio, rej, steps = np.empty(N), np.empty(N, dtype=np.uint8), np.empty(N, dtype=np.int32)
+    rc = lib().oracle_hmc_iter_dyn(C.byref(st), C.c_int(LEAPFROG), _ptr(q), _ptr(p), _ptr(u), _ptr(m),
+                                   C.c_int64(N), C.c_int64(N), C.c_double(h), C.c_int(L), C.c_int(compat),
+                                   C.c_double(beta), _ptr(si), C.c_int(1 if uturn else 0), _ptr(steps),
+                                   _ptr(ratio), _ptr(rej))
+    assert rc == 0
+    return ratio, rej.astype(bool), steps
+
+
+def philox_steps(seed, it, chain0, N, L):
+    out = np.empty(N, dtype=np.int32)
+    lib().oracle_philox_steps(C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0), C.c_int64(N), C.c_int(L),
+                              _ptr(out))
+    return out
+
+
 def hmc_iter(pot, method, q, p, u, mass, h, L, compat=COMPAT_P_FROM_OLDQ, beta=1.0):
     """One getSamples iteration, in place on q (state) and p (drawn momentum).
     Returns (ratio, reject_mask).  beta != 1: the build's PBBI_BETA_ACCEPT accept test."""

@@ -219,6 +219,33 @@ static void leapfrog_chain(const oracle_pot* P, double* q, double* p, double* v,
     for (int d = 0; d < D; ++d) p[d] = v[d] * m;
 }
 
+/* Leapfrog with the chain's OWN step count (the build's PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP,
+ * include/pbbi.h; planned in the reference's WeekPlan.md:16-17, not a reference feature): the loop
+ * of leapfrog_chain above, at most Ln steps, and under `uturn` left after the first step j at which
+ * (q_j - q_0) . v_j < 0 (sequential sum over the dimensions; p = v*m has v's sign).  Returns the
+ * steps taken. */
+static int leapfrog_chain_dyn(const oracle_pot* P, double* q, double* p, double* v, double m, double h,
+                              int Ln, int uturn, double* a, double* an, double* tmp, double* q0) {
+    const int D = P->D;
+    const double h2 = h * h;
+    int steps = 0;
+    for (int d = 0; d < D; ++d) v[d] = p[d] / m;
+    for (int d = 0; d < D; ++d) q0[d] = q[d];
+    accel(P, q, m, a, tmp);
+    while (steps < Ln) {
+        for (int d = 0; d < D; ++d) q[d] += (v[d] * h + (0.5 * a[d]) * h2);
+        accel(P, q, m, an, tmp);
+        for (int d = 0; d < D; ++d) v[d] += (0.5 * (a[d] + an[d])) * h;
+        for (int d = 0; d < D; ++d) a[d] = an[d];
+        ++steps;
+        double dot = 0.0;
+        for (int d = 0; d < D; ++d) dot += (q[d] - q0[d]) * v[d];
+        if (uturn && dot < 0.0) break;
+    }
+    for (int d = 0; d < D; ++d) p[d] = v[d] * m;
+    return steps;
+}
+
 /* One chain of StormerVerlet.integrate                   src/integrator.py:142-163
  *   v = p/m; qPast = q; q = q + v*h + (0.5*a(q))*h**2
  *   repeat L: tmp = q; q = 2*q - qPast + a(q)*h**2; qPast = tmp
@@ -346,6 +373,12 @@ int oracle_weights_ratio(const oracle_pot* P, const double* newQ, const double* 
 int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, const double* u,
                          const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
                          double beta, double* ratio_out, unsigned char* reject_out);
+/* ... and with per-chain trajectory lengths: steps_in (N, each clamped to [0, L]; NULL = L), `uturn`
+ * (stop at the first U-turn), steps_out (N, optional).  Leapfrog only when either is in use. */
+int oracle_hmc_iter_dyn(const oracle_pot* P, int method, double* q, double* p, const double* u,
+                        const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
+                        double beta, const int32_t* steps_in, int uturn, int32_t* steps_out,
+                        double* ratio_out, unsigned char* reject_out);
 
 int oracle_hmc_iter(const oracle_pot* P, int method, double* q, double* p, const double* u,
                     const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
@@ -356,13 +389,23 @@ int oracle_hmc_iter(const oracle_pot* P, int method, double* q, double* p, const
 int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, const double* u,
                          const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
                          double beta, double* ratio_out, unsigned char* reject_out) {
+    return oracle_hmc_iter_dyn(P, method, q, p, u, mass, N, ldn, h, L, compat, beta, NULL, 0, NULL, ratio_out,
+                               reject_out);
+}
+
+int oracle_hmc_iter_dyn(const oracle_pot* P, int method, double* q, double* p, const double* u,
+                        const double* mass, int64_t N, int64_t ldn, double h, int L, int compat,
+                        double beta, const int32_t* steps_in, int uturn, int32_t* steps_out,
+                        double* ratio_out, unsigned char* reject_out) {
     const int D = P->D;
+    const int dyn = (steps_in != NULL) || uturn;
+    if (dyn && method != METHOD_LEAPFROG) return -2;
     if (D > ORACLE_MAXD || L < 0) return -1;
 #pragma omp parallel
     {
-        double* buf = (double*)malloc(sizeof(double) * 8 * D);
+        double* buf = (double*)malloc(sizeof(double) * 9 * D);
         double *qc = buf, *pc = buf + D, *vc = buf + 2 * D, *a = buf + 3 * D, *b = buf + 4 * D,
-               *tmp = buf + 5 * D, *oq = buf + 6 * D, *op = buf + 7 * D;
+               *tmp = buf + 5 * D, *oq = buf + 6 * D, *op = buf + 7 * D, *q0 = buf + 8 * D;
 #pragma omp for schedule(static)
         for (int64_t n = 0; n < N; ++n) {
             const double m = mass ? mass[n] : 1.0;
@@ -370,7 +413,12 @@ int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, 
             col_get(p, D, ldn, n, pc);
             memcpy(oq, qc, sizeof(double) * D); /* oldQ = np.copy(q)  :156 */
             memcpy(op, pc, sizeof(double) * D); /* oldP = np.copy(p)  :157 */
-            if (method == METHOD_LEAPFROG)
+            int taken = L;
+            if (dyn) {
+                int Ln = steps_in ? steps_in[n] : L;
+                Ln = Ln < 0 ? 0 : (Ln > L ? L : Ln);
+                taken = leapfrog_chain_dyn(P, qc, pc, vc, m, h, Ln, uturn, a, b, tmp, q0);
+            } else if (method == METHOD_LEAPFROG)
                 leapfrog_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
             else
                 stormer_verlet_chain(P, qc, pc, vc, m, h, L, a, b, tmp);
@@ -390,6 +438,7 @@ int oracle_hmc_iter_beta(const oracle_pot* P, int method, double* q, double* p, 
             }
             if (ratio_out) ratio_out[n] = ratio;
             if (reject_out) reject_out[n] = (unsigned char)reject;
+            if (steps_out) steps_out[n] = taken;
         }
         free(buf);
     }
@@ -468,6 +517,17 @@ static double rng_uniform(uint64_t seed, uint64_t iter, uint64_t chain) {
     uint32_t x[4];
     rng_block(seed, STREAM_UNIFORM, iter, chain, 0xFFFFFFFFu, x);
     return u53(x[0], x[1]);
+}
+
+/* PBBI_PER_CHAIN_STEPS draw (include/pbbi.h): 1 + floor(u * L) capped at L, u from STREAM_STEPS = 3 */
+int oracle_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int L, int32_t* out) {
+    for (int64_t n = 0; n < N; ++n) {
+        uint32_t x[4];
+        rng_block(seed, 3u, iter, chain0 + n, 0xFFFFFFFFu, x);
+        int s = 1 + (int)(u53(x[0], x[1]) * (double)L);
+        out[n] = L > 0 ? (s > L ? L : s) : 0;
+    }
+    return 0;
 }
 
 /* out[d*ldn + n] = scale_n * z(d, chain0 + n); scale (N) optional else scalar */

@@ -242,7 +242,7 @@ class HMC:
 
     # ------------------------------------------------------------------ sampling
     def getSamples(self, numSamples, temperature, qStd, rng=None, seed=None, device_output=False,
-                   chain0=0, iter0=0, host_stream=None, jitter=0.0, burn_in=0):
+                   chain0=0, iter0=0, host_stream=None, jitter=0.0, burn_in=0, per_chain_steps=False):
         """HMC.getSamples (src/HMC.py:123-183): returns (samples_hmc, momentum_hmc), each
         (D, N, numSamples) with the sample index fastest.
 
@@ -258,7 +258,10 @@ class HMC:
         trajectory lengths is still a valid HMC kernel.  burn_in (rng="philox" only) runs that many
         unrecorded iterations first (draw indices iter0 .. iter0+burn_in-1; the recorded ones
         follow), without sample or momentum slabs: getSamples(S, burn_in=B) equals the last S
-        draws of getSamples(B + S).
+        draws of getSamples(B + S).  per_chain_steps=True (rng="philox", Leapfrog; PBBI_PER_CHAIN_STEPS,
+        include/pbbi.h) gives every CHAIN its own number of leapfrog steps in every iteration, uniform
+        on [1, numSteps] from the Philox stream: randomised-length HMC per chain, inside the fused
+        kernels (finished chains are masked out); self.steps holds the (S, N) counts.
         """
         pot = self._pot
         ens = self.ensemble
@@ -282,8 +285,10 @@ class HMC:
 
         if self.verbose:
             self.print_information()
-        if rng == "numpy" and (burn_in or jitter):
-            raise ValueError("burn_in / jitter need rng='philox' (the parity mode replays the reference's stream)")
+        if rng == "numpy" and (burn_in or jitter or per_chain_steps):
+            raise ValueError("burn_in / jitter / per_chain_steps need rng='philox' (the parity mode replays "
+                             "the reference's stream)")
+        self.steps = None
         if rng == "numpy":
             # identical RNG consumption to the reference: q0, then per iteration p then u
             if host_stream is None:
@@ -333,6 +338,9 @@ class HMC:
                           mptr, None, None, None, None, N, N, h, L, int(burn_in), flags, seed,
                           int(iter0), int(chain0), kT, stream)
                 iter0 = int(iter0) + int(burn_in)
+            if jitter and per_chain_steps:
+                raise ValueError("jitter (one length per iteration) and per_chain_steps (one per chain) "
+                                 "are alternatives")
             if jitter and S > 0:
                 if not 0.0 < jitter < 1.0:
                     raise ValueError("jitter must be in (0, 1)")
@@ -344,6 +352,13 @@ class HMC:
                               mptr, samples[i].data_ptr(), momenta[i].data_ptr(), reject[i].data_ptr(),
                               ratio[i].data_ptr(), N, N, h, int(steps[int(iter0) + i]), 1, flags, seed,
                               int(iter0) + i, int(chain0), kT, stream)
+            elif per_chain_steps:
+                steps = empty((S, N), np.int32, dev)
+                _lib.call("pbbi_hmc_run_dyn", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                          mptr, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
+                          ratio.data_ptr(), steps.data_ptr(), N, N, h, L, S, flags | _lib.PER_CHAIN_STEPS,
+                          seed, int(iter0), int(chain0), kT, stream)
+                self.steps = to_numpy(steps)
             else:
                 _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(),
                           mptr, samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(),
@@ -469,6 +484,41 @@ class HMC:
         self.stepSize = self.integrator.stepSize = h
         self.integrator.numSteps = max(1, int(self.simulTime / h))  # what the warm-up itself ran
         return h
+
+    def adaptTrajectoryLength(self, temperature, qStd, iterations=12, max_steps=None, quantile=0.5,
+                              seed=None, chain0=0):
+        """Trajectory length from the no-U-turn criterion, measured on the ENSEMBLE (the
+        reference's WeekPlan.md:16-17 plans "no u-turn sampling"): `iterations` warm-up iterations run with
+        PBBI_UTURN_STOP -- every chain integrates until (q - q0).p < 0, its lane masked out from then on,
+        at most max_steps (default 8 x the current numSteps) -- and the `quantile` of the chains' U-turn
+        step counts over the second half of the warm-up becomes numSteps (simulTime = numSteps*stepSize).
+        Stopping at a U-turn is not a reversible move, so these iterations only MEASURE: the recorded run
+        afterwards uses the fixed (or jittered / per-chain random) length, which is.  Elementwise
+        potentials with D <= 32 (include/pbbi.h); the warm-up state is discarded.  Returns simulTime."""
+        pot, ens = self._pot, self.ensemble
+        D, N = ens.numDimensions, ens.numParticles
+        if N == 0:
+            return float(self.simulTime)
+        seed = ((self.seed if seed is None else int(seed)) ^ WARMUP_SEED_MASK) & 0xFFFFFFFFFFFFFFFF
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+        kT = float(boltzmannConst * temperature)
+        Lmax = int(max_steps) if max_steps else max(8, 8 * int(self.integrator.numSteps))
+        q_state = empty((D, N), dt, dev)
+        steps = empty((int(iterations), N), np.int32, dev)
+        md = self._mass()
+        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, int(chain0), D, N, N, float(qStd), None,
+                  pot._dt, dev, q_state.data_ptr(), stream)
+        _lib.call("pbbi_hmc_run_dyn", pot.handle, self.integrator.method_id, q_state.data_ptr(),
+                  md.data_ptr() if md is not None else None, None, None, None, None, steps.data_ptr(), N, N,
+                  float(self.stepSize), Lmax, int(iterations),
+                  (self._flags() & ~_lib.COMPAT_P_FROM_OLDQ) | _lib.UTURN_STOP, seed, 0, int(chain0), kT, stream)
+        st = to_numpy(steps)[int(iterations) // 2:]
+        self.uturn_steps = st
+        L = int(max(1, round(float(np.quantile(st, quantile)))))
+        self.integrator.numSteps = L
+        self.simulTime = self.integrator.finalTime = L * float(self.stepSize)
+        return self.simulTime
 
     def sampleMoments(self, samples_dns):
         """Per-dimension (mean, variance) over every draw of every chain, computed on the GPU from

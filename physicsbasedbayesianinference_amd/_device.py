@@ -31,7 +31,7 @@ def default_device():
 def torch_dtype(np_dtype):
     t = torch()
     return {np.dtype("float64"): t.float64, np.dtype("float32"): t.float32,
-            np.dtype("uint8"): t.uint8}[np.dtype(np_dtype)]
+            np.dtype("uint8"): t.uint8, np.dtype("int32"): t.int32}[np.dtype(np_dtype)]
 
 
 def dev(device):

@@ -16,7 +16,9 @@ LEAPFROG, STORMER_VERLET = 0, 1
 COMPAT_P_FROM_OLDQ = 1
 KDK_FMA = 2
 BETA_ACCEPT = 4
-STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
+PER_CHAIN_STEPS = 8
+UTURN_STOP = 16
+STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM, STREAM_STEPS = 0, 1, 2, 3
 
 
 class PbbiError(RuntimeError):
@@ -57,6 +59,10 @@ PROTOTYPES = {
     "pbbi_weights_ratio": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "pbbi_hmc_iter": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _vp],
     "pbbi_hmc_iter_kt": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _d, _vp],
+    "pbbi_hmc_iter_dyn": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _d, _vp],
+    "pbbi_hmc_run_dyn": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64,
+                         _u64, _d, _vp],
+    "pbbi_philox_steps": [_u64, _u64, _u64, _i64, _i, _i, _vp, _vp],
     "pbbi_hmc_run": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64,
                      _u64, _d, _vp],
     "pbbi_philox_normal": [_u64, _i, _u64, _u64, _i, _i64, _i64, _d, _vp, _i, _i, _vp, _vp],

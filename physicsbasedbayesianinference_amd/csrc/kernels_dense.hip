@@ -108,6 +108,8 @@ struct DensePrm {
     double h, cst, kT;
     int L, D, flags, rng, mode;  // mode 0: HMC iteration, 1: integrate only (in place)
     uint64_t seed, iter, chain0;
+    const int32_t* steps_in;  // PBBI_PER_CHAIN_STEPS, uploaded mode (nullptr: L)
+    int32_t* steps_out;
 };
 
 template <int NT>
@@ -506,7 +508,12 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 //   d = q_n - q_{n-1} = vh*h:  vh_1 = v_0 + (0.5*a_0)*h;  q_{n+1} = q_n + vh*h;  vh += a_n*h
 // i.e. kick-drift-kick WITHOUT the final half kick and with L+1 drifts; its returned velocity
 // (q_{L+1} - q_L)/h is vh itself.  U(q_new) then needs one more mat-vec at q_{L+1}.
-template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG>
+// DYN (PBBI_PER_CHAIN_STEPS, Leapfrog, MODE 0): chain c takes L_c <= L steps.  The tile runs the
+// largest L_c of the wave's 16 chains; a chain that has finished is frozen by per-lane coefficients
+// (drift step 0, kick 0) instead of a branch around the register arrays, its last kick is its own
+// half kick, and x.g for H_new is taken at the wave's last step, where every frozen chain still
+// holds its final position.
+template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, bool DYN = false>
 __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
@@ -611,11 +618,29 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
     STAMP(4);
     xg = 0.0;
-    for (int j = 0; j < prm.L; ++j) {
-        const bool last = (j == prm.L - 1) && METHOD == PBBI_LEAPFROG;
-        const double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
+    int Ln = prm.L, Lw = prm.L;  // this chain's steps, the wave's
+    if constexpr (DYN) {
+        if (rng) Ln = rng_steps(prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc), prm.L);
+        else if (prm.steps_in) Ln = prm.steps_in[n0 + cc];
+        Ln = Ln < 1 ? 1 : (Ln > prm.L ? prm.L : Ln);
+        Lw = Ln;
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) {  // the 16 chains of the wave (lanes that differ in bits 0-3)
+            const int o = __shfl_xor(Lw, sft, 64);
+            Lw = o > Lw ? o : Lw;
+        }
+        Lw = __builtin_amdgcn_readfirstlane(Lw);
+    }
+    for (int j = 0; j < Lw; ++j) {
+        const bool last = (j == Lw - 1) && METHOD == PBBI_LEAPFROG;
+        double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
+        double hq = h;
+        if constexpr (DYN) {
+            cj = j < Ln ? (j == Ln - 1 ? ckh : ck) : 0.0;
+            hq = j < Ln ? h : 0.0;
+        }
         STAMP(5 + 2 * j);
-        matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, h);  // drift + g(q_{j+1})
+        matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, hq);  // drift + g(q_{j+1})
         if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
         kick_pass<NT, NTP, 0>(vh, acc, cj);
         STAMP(6 + 2 * j);
@@ -695,6 +720,9 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         if (valid && g == 0) {
             if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
             if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+            if constexpr (DYN) {
+                if (prm.steps_out) prm.steps_out[n0 + c] = Ln;
+            }
         }
         STAMP(41);
     }
@@ -816,9 +844,14 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const int64_t tiles2 = (N + CHAINS_PER_WG2 - 1) / CHAINS_PER_WG2;
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
         const bool zmean = pot->zero_mean;
+        const bool dyn = prm.mode == 0 && (prm.flags & PBBI_PER_CHAIN_STEPS) != 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
-        if (method == PBBI_LEAPFROG) {                                                            \
+        if (dyn && M_ == 0) {                                                                     \
+            if (int rc = set_lds(k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG) {                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>, lds)) return rc;    \
             hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>), grid2, block2, lds, \
                                stream, prm);                                                      \
@@ -926,6 +959,11 @@ int dense_build_fragments(pbbi_potential* pot, const double* P, const double* me
 
 int dense_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
+    if (a.flags & PBBI_UTURN_STOP)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "PBBI_UTURN_STOP is not served by the dense MFMA kernel (the start "
+                                               "point does not fit its registers); PBBI_PER_CHAIN_STEPS is");
+    if ((a.flags & PBBI_PER_CHAIN_STEPS) && (a.method != PBBI_LEAPFROG || a.L < 1))
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "PBBI_PER_CHAIN_STEPS on the dense kernel: Leapfrog with L >= 1");
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
     DensePrm prm{};
@@ -947,6 +985,7 @@ int dense_hmc_iter(const IterArgs& a) {
     prm.h = a.h; prm.cst = a.pot->cst; prm.kT = a.kT;
     prm.L = a.L; prm.D = a.pot->D; prm.flags = a.flags; prm.rng = a.rng; prm.mode = 0;
     prm.seed = a.seed; prm.iter = a.iter; prm.chain0 = a.chain0;
+    prm.steps_in = a.steps_in; prm.steps_out = a.steps_out;
     return launch_traj(a.pot, a.method, prm, a.N, a.stream);
 }
 

@@ -313,6 +313,122 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
 }
 
+// ---- per-chain trajectory lengths (PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP, include/pbbi.h) -------
+// Leapfrog.integrate (src/integrator.py:105-120) with the step count of every chain its own: lane n
+// takes steps while j < L_n and, under PBBI_UTURN_STOP, until (q_j - q_0) . v_j < 0 (p = v*m has v's
+// sign).  The velocity-Verlet form has the synchronised velocity after every step, so the test costs
+// one dot product; q_0 rides in p[] (dead between v = p/m and p = v*m).  Finished lanes are masked
+// out by the branch; the loop ends for the wave when no lane is active.  Same operation order as
+// integrate_chain -> bit-exact with the oracle's leapfrog_chain_dyn, step counts included.
+template <typename T, typename Pot, int DMAX, bool UNIT>
+__device__ __forceinline__ int integrate_chain_dyn(const Pot& pot, T (&q)[DMAX], T (&p)[DMAX], T (&v)[DMAX],
+                                                   T m, T h, int Ln, bool uturn) {
+    const T hh2 = T(0.5) * (h * h), hh = T(0.5) * h;
+    T a[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        v[d] = UNIT ? p[d] : p[d] / m;
+        p[d] = q[d];  // q_0
+    }
+    pot.grad_each(q, [&](int d, T g) { a[d] = UNIT ? -g : -g / m; });
+    int steps = 0;
+    bool active = Ln > 0;
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {  // wave-uniform: until the wave's last chain stops
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) q[d] += (v[d] * h + a[d] * hh2);
+            pot.grad_each(q, [&](int d, T g) {
+                const T an = UNIT ? -g : -g / m;
+                v[d] += (a[d] + an) * hh;
+                a[d] = an;
+            });
+            ++steps;
+            T dot = T(0);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) dot += (q[d] - p[d]) * v[d];
+            active = steps < Ln && !(uturn && dot < T(0));
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) p[d] = UNIT ? v[d] : v[d] * m;
+    return steps;
+}
+
+template <typename T>
+struct DynPrm {
+    HmcPrm<T> b;
+    const int32_t* steps_in;
+    int32_t* steps_out;
+};
+
+template <typename T, typename Pot, int DMAX, bool FULL, bool UNIT>
+__global__ void __launch_bounds__(BLOCK) k_lane_dyn_hmc(DynPrm<T> dp, Pot pot) {
+    const HmcPrm<T>& prm = dp.b;
+    const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t n = n0 + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    const uint64_t chain = prm.chain0 + (uint64_t)n;
+    const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
+    const uint32_t rin = (uint32_t)prm.ldn_in * (uint32_t)sizeof(T);
+    const uint32_t rout = (uint32_t)prm.ldn_out * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q_in, D, prm.ldn_in, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bp = rows_rsrc<T, FULL>(prm.p_in, D, prm.ldn_in, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bqo = rows_rsrc<T, FULL>(prm.q_out, D, prm.ldn_out, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(prm.p_out, D, prm.ldn_out, prm.N, n0);
+    const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
+
+    T q[DMAX], p[DMAX], v[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, rin, d, D);
+    T u;
+    int Ln = prm.L;
+    if (prm.rng) {
+        draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
+        u = (T)rng_uniform(prm.seed, prm.iter, chain);
+        if (prm.flags & PBBI_PER_CHAIN_STEPS) Ln = prm.L > 0 ? rng_steps(prm.seed, prm.iter, chain, prm.L) : 0;
+    } else {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
+        u = prm.u_in[n];
+        if ((prm.flags & PBBI_PER_CHAIN_STEPS) && dp.steps_in) {
+            Ln = dp.steps_in[n];
+            Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
+        }
+    }
+    const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+    const int steps = integrate_chain_dyn<T, Pot, DMAX, UNIT>(pot, q, p, v, m, prm.h, Ln,
+                                                              (prm.flags & PBBI_UTURN_STOP) != 0);
+    const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
+    const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+    if (reject) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, rin, d, D);  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) p[d] = q[d];
+            } else if (prm.rng) {
+                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
+            } else {
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
+    if (prm.p_out) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
+    }
+    if (prm.ratio_out) prm.ratio_out[n] = ratio;
+    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+    if (dp.steps_out) dp.steps_out[n] = steps;
+}
+
 template <typename T>
 struct IntPrm {
     T* q;
@@ -557,6 +673,7 @@ inline bool streams(const pbbi_potential* pot) { return pot->dtype != PBBI_F64 |
 }  // namespace
 
 int lane_hmc_iter(const IterArgs& a) {
+    if (pbbi_dyn(a)) return lane_dyn_hmc_iter(a);
     if (sepn_applies(a)) return sepn_hmc_iter(a);
     if (rosg_applies(a)) return rosg_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 32 < D <= 128: 4 / 8 lanes of one wave
     if (rosn_applies(a)) return rosn_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 128 < D <= 256: parts in waves  // PBBI_KDK_FMA, separable, 16 < D <= 256
@@ -567,11 +684,48 @@ int lane_hmc_iter(const IterArgs& a) {
     if (!no_lane2 && lane2_applies(a)) return lane2_hmc_iter(a);
     return launch_hmc<double>(a);
 }
+int lane_dyn_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (pot->dtype != PBBI_F64 || pot->D > 32 || a.method != PBBI_LEAPFROG)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED,
+                         "per-chain trajectory lengths: the chain-per-lane kernels take fp64, D <= 32, Leapfrog");
+    if (int rc = check_ld(pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    typedef double T;
+    DynPrm<T> prm{{(const T*)a.q_in, (const T*)a.p_in, (const T*)a.u_in, (const T*)a.mass, (T*)a.q_out,
+                   (T*)a.p_out, (T*)a.ratio_out, a.reject_out, a.N, a.ldn_in, a.ldn_out, (T)a.h, a.L, pot->D,
+                   a.flags, a.rng, a.seed, a.iter, a.chain0, a.kT},
+                  a.steps_in, a.steps_out};
+    const dim3 grid = grid_for(a.N);
+    with_dmax(pot->D, [&](auto dm) {
+        constexpr int DM = decltype(dm)::value;
+        if constexpr (DM <= 32) {
+            with_bool(pot->D == DM, [&](auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                with_bool(a.mass == nullptr, [&](auto unit) {
+                    constexpr bool UNIT = decltype(unit)::value;
+                    if (pot->kind == KIND_ROSENBROCK) {
+                        auto f = make_ros<T, DM, FULL>(pot);
+                        hipLaunchKernelGGL((k_lane_dyn_hmc<T, decltype(f), DM, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                                           a.stream, prm, f);
+                    } else {
+                        auto f = make_sep<T, DM, FULL>(pot);
+                        hipLaunchKernelGGL((k_lane_dyn_hmc<T, decltype(f), DM, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                                           a.stream, prm, f);
+                    }
+                });
+            });
+        }
+    });
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
 int lane_fused_iterations(const IterArgs& a) {
     // only the two-lane Rosenbrock kernel keeps a chain in registers across iterations so far
     static const int fuse = getenv("PBBI_FUSE_ITERS") ? atoi(getenv("PBBI_FUSE_ITERS")) : 16;
     static const bool no_lane2 = (getenv("PBBI_NO_LANE2") != nullptr);
-    if (fuse <= 1 || no_lane2 || !a.rng || a.N == 0 || !lane2_applies(a) || streams(a.pot)) return 1;
+    if (fuse <= 1 || no_lane2 || !a.rng || a.N == 0 || pbbi_dyn(a) || !lane2_applies(a) || streams(a.pot)) return 1;
     if (check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) != PBBI_OK) return 1;
     return fuse;
 }

@@ -134,6 +134,9 @@ int plugin_rc(int rc) {
 }
 int route_hmc(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
+    if (pbbi_dyn(a) && (pot->kind == KIND_CUSTOM || is_big(pot)))
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths are served by the chain-per-lane "
+                                               "kernels (D <= 32) and the dense kernel (D <= 128) only");
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
     return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
 }
@@ -175,6 +178,16 @@ template <typename T>
 __global__ void k_philox_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, T* out) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n < N) out[n] = (T)rng_uniform(seed, iter, chain0 + n);
+}
+
+__global__ void k_fill_i32(int32_t* out, int64_t N, int value) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = value;
+}
+
+__global__ void k_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int L, int32_t* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = L > 0 ? rng_steps(seed, iter, chain0 + n, L) : 0;
 }
 
 // (S, D*N) -> (D*N, S) tiled transpose through LDS: both sides coalesced.
@@ -633,6 +646,32 @@ int pbbi_hmc_iter(const pbbi_potential* pot, int method, const void* q_in, const
     return route_hmc(a);
 }
 
+int pbbi_hmc_iter_dyn(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
+                      const void* u_in, const void* mass, const int32_t* steps_in, void* q_out, void* p_out,
+                      void* ratio_out, uint8_t* reject_out, int32_t* steps_out, int64_t N, int64_t ldn,
+                      double h, int L, int flags, double kT, void* stream) {
+    if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    if ((!q_in || !p_in || !u_in || !q_out) && N > 0)
+        return pbbi_fail(PBBI_ERR_INVALID, "q_in / p_in / u_in / q_out must be non-NULL");
+    if (!(kT > 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be > 0");
+    if (method != PBBI_LEAPFROG) return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths: Leapfrog only");
+    DeviceGuard guard(pot->device);
+    IterArgs a{};
+    a.pot = pot; a.method = method; a.q_in = q_in; a.p_in = p_in; a.u_in = u_in; a.mass = mass;
+    a.q_out = q_out; a.p_out = p_out; a.ratio_out = ratio_out; a.reject_out = reject_out;
+    a.N = N; a.ldn_in = ldn; a.ldn_out = ldn; a.h = h; a.L = L; a.flags = flags;
+    a.rng = 0; a.kT = kT; a.stream = (hipStream_t)stream;
+    a.steps_in = steps_in; a.steps_out = steps_out;
+    if (!pbbi_dyn(a)) {  // plain iteration: every chain takes L steps
+        if (steps_out && N > 0) {
+            const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+            hipLaunchKernelGGL(k_fill_i32, grid, block, 0, a.stream, steps_out, N, L);
+        }
+        a.steps_in = nullptr; a.steps_out = nullptr;
+    }
+    return route_hmc(a);
+}
+
 int pbbi_hmc_iter_kt(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
                      const void* u_in, const void* mass, void* q_out, void* p_out, void* ratio_out,
                      uint8_t* reject_out, int64_t N, int64_t ldn, double h, int L, int flags, double kT,
@@ -654,7 +693,20 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
                  void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
                  int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
                  uint64_t iter0, uint64_t chain0, double kT, void* stream) {
+    if (flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP))
+        return pbbi_fail(PBBI_ERR_INVALID, "per-chain trajectory lengths go through pbbi_hmc_run_dyn");
+    return pbbi_hmc_run_dyn(pot, method, q_state, mass, samples_out, momenta_out, reject_out, ratio_out, nullptr,
+                            N, ldn, h, L, S, flags, seed, iter0, chain0, kT, stream);
+}
+
+int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const void* mass,
+                     void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
+                     int32_t* steps_out, int64_t N, int64_t ldn, double h, int L, int S, int flags,
+                     uint64_t seed, uint64_t iter0, uint64_t chain0, double kT, void* stream) {
     if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    const bool dyn = (flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0;
+    if (dyn && method != PBBI_LEAPFROG)
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths: Leapfrog only");
     if (S < 0) return pbbi_fail(PBBI_ERR_INVALID, "S must be >= 0");
     if (!q_state && N > 0 && S > 0) return pbbi_fail(PBBI_ERR_INVALID, "q_state must be non-NULL");
     if (!samples_out && momenta_out)
@@ -699,6 +751,11 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = st;
         a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
+        if (steps_out) {
+            if (dyn) a.steps_out = steps_out + (size_t)i * N;
+            else hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                                    steps_out + (size_t)i * N, N, L);
+        }
         // kernels that keep the chain on chip take several iterations per launch
         int chunk = route_fused_iterations(a);
         if (chunk > S - i) chunk = S - i;
@@ -743,6 +800,19 @@ int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t ch
                            (float*)out);
     else
         return pbbi_fail(PBBI_ERR_INVALID, "unknown dtype");
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+int pbbi_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, int L, int device,
+                      int32_t* out, void* stream) {
+    if (N < 0 || L < 0) return pbbi_fail(PBBI_ERR_INVALID, "bad N / L");
+    if (iter > UINT32_MAX) return pbbi_fail(PBBI_ERR_INVALID, "iter must be < 2^32");
+    if (!out && N > 0) return pbbi_fail(PBBI_ERR_INVALID, "out is NULL");
+    if (N == 0) return PBBI_OK;
+    DeviceGuard guard(device);
+    hipLaunchKernelGGL(k_philox_steps, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       iter, chain0, N, L, out);
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

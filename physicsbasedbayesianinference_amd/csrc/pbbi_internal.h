@@ -109,7 +109,11 @@ struct IterArgs {
     int fuse_wrap2;
     int64_t fuse_slab0;
     void* fuse_q_base;
+    // per-chain trajectory lengths (PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP, pbbi_hmc_*_dyn)
+    const int32_t* steps_in;  // uploaded mode; nullptr = L
+    int32_t* steps_out;       // optional
 };
+inline bool pbbi_dyn(const IterArgs& a) { return (a.flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0; }
 
 struct IntegrateArgs {
     const pbbi_potential* pot;
@@ -178,6 +182,8 @@ int lane2_hmc_iter(const IterArgs& a);
 // how many consecutive iterations of pbbi_hmc_run one call of route_hmc may cover for these arguments
 // (1 = the path has no fused form); lane_fused_iterations: kernels_lane.hip
 int lane_fused_iterations(const IterArgs& a);
+// per-chain trajectory lengths (k_lane_dyn_hmc: elementwise potentials, fp64, D <= 32, Leapfrog)
+int lane_dyn_hmc_iter(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
 bool sepn_applies(const IterArgs& a);
 int sepn_hmc_iter(const IterArgs& a);

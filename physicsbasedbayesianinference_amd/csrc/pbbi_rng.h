@@ -104,6 +104,13 @@ __device__ __forceinline__ double rng_normal(uint64_t seed, uint32_t stream, uin
     return (double)(slot == 0 ? z[0] : slot == 1 ? z[1] : slot == 2 ? z[2] : z[3]);
 }
 
+// PBBI_PER_CHAIN_STEPS: the chain's own number of leapfrog steps, 1 + floor(u * L) capped at L
+__device__ __forceinline__ int rng_steps(uint64_t seed, uint64_t iter, uint64_t chain, int L) {
+    const PhiloxOut x = rng_block(seed, /*PBBI_STREAM_STEPS*/ 3u, iter, chain, 0xFFFFFFFFu);
+    const int s = 1 + (int)(u53(x.x0, x.x1) * (double)L);
+    return s > L ? L : s;
+}
+
 __device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t iter, uint64_t chain) {
     const PhiloxOut x = rng_block(seed, /*PBBI_STREAM_UNIFORM*/ 2u, iter, chain, 0xFFFFFFFFu);
     return u53(x.x0, x.x1);

@@ -1695,3 +1695,133 @@ def test_sample_covariance_and_ess_match_numpy(P, lib):
     assert np.all(np.abs(ess[ok] / expect[ok] - 1.0) < 0.15), ess / expect
     with pytest.raises(lib.PbbiError):
         lib.call("pbbi_chain_autocov", xd.data_ptr(), cm.data_ptr(), S, D, N, 33, lib.F64, 0, acov.data_ptr(), stream_ptr(0))
+
+
+# ------------------------------------------------------------------ per-chain trajectory lengths
+def _dyn_case(P, case, rs):
+    if case == "diag5":
+        D, mu, prec = 5, rs.standard_normal(5), rs.uniform(0.5, 2, 5)
+        return D, P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec), 0.1
+    if case == "diag30":
+        D, mu, prec = 30, rs.standard_normal(30), rs.uniform(0.5, 2, 30)
+        return D, P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec), 0.1
+    if case == "harm3":
+        k = np.array([2.0, 3.0, 0.5])
+        return 3, P.Harmonic(k), orc.pot_harmonic(k), 0.1
+    if case == "ros12":
+        return 12, P.Rosenbrock(12), orc.pot_rosenbrock(12), 0.03
+    if case == "ros32":
+        return 32, P.Rosenbrock(32), orc.pot_rosenbrock(32), 0.03
+    D = int(case[5:])
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm, mu = 0.5 * (Pm + Pm.T), rs.standard_normal(D)
+    return D, P.GaussianDense(mu, precision=Pm, const=0.0), orc.pot_gauss_dense(mu, Pm), 0.1
+
+
+@pytest.mark.parametrize("case,mass", [("diag5", False), ("diag30", True), ("harm3", True), ("ros12", False),
+                                       ("ros32", True)])
+@pytest.mark.parametrize("mode", ["steps", "uturn", "both"])
+def test_per_chain_steps_lane_kernels_bitexact(P, lib, case, mass, mode):
+    """pbbi_hmc_iter_dyn on the chain-per-lane kernels: per-chain step counts (uploaded) and / or the
+    U-turn stop, against the oracle's leapfrog_chain_dyn -- step counts, decisions, q and p bit for bit."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(len(case) * 7 + len(mode))
+    D, pot, op, h = _dyn_case(P, case, rs)
+    N, L = 777, 40
+    q0 = (1.0 if "ros" in case else 0.0) + 0.5 * rs.standard_normal((D, N))
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    p0 = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+    u = rs.uniform(size=N)
+    steps_in = rs.randint(0, L + 3, size=N).astype(np.int32) if mode != "uturn" else None  # some beyond L: clamped
+    flags = lib.COMPAT_P_FROM_OLDQ | (lib.PER_CHAIN_STEPS if mode != "uturn" else 0) | \
+        (lib.UTURN_STOP if mode != "steps" else 0)
+    qd, pd, ud = (as_device(x, 0, np.float64) for x in (q0, p0, u))
+    md = as_device(m, 0, np.float64) if mass else None
+    sd = torch.tensor(steps_in, device="cuda") if steps_in is not None else None
+    qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
+    ro, rj, so = empty((N,), np.float64, 0), empty((N,), np.uint8, 0), empty((N,), np.int32, 0)
+    lib.call("pbbi_hmc_iter_dyn", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+             md.data_ptr() if mass else None, sd.data_ptr() if sd is not None else None, qo.data_ptr(),
+             po.data_ptr(), ro.data_ptr(), rj.data_ptr(), so.data_ptr(), N, N, h, L, flags, 1.0, stream_ptr(0))
+    torch.cuda.synchronize()
+    q_or, p_or = q0.copy(), p0.copy()
+    r_or, rej_or, st_or = orc.hmc_iter_dyn(op, q_or, p_or, u, m, h, L, steps_in=steps_in, uturn=(mode != "steps"))
+    assert np.array_equal(to_numpy(so), st_or)
+    assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
+    assert np.array_equal(to_numpy(qo), q_or) and np.array_equal(to_numpy(po), p_or)
+    if mode != "steps":
+        assert len(np.unique(st_or)) > 3                          # genuinely divergent lengths inside a wave
+    if mode == "uturn":
+        assert st_or.min() >= 1
+    if mode == "steps":
+        assert np.array_equal(st_or, np.clip(steps_in, 0, L))
+
+
+@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False)])
+@pytest.mark.parametrize("rng", ["upload", "philox"])
+def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
+    """PBBI_PER_CHAIN_STEPS on the dense MFMA kernel (finished chains frozen by per-lane coefficients, the
+    tile runs its longest chain): counts, decisions and states against the oracle; U-turn stop refused."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(5)
+    D, pot, op, h = _dyn_case(P, case, rs)
+    N, L, seed = 333, 9, 21
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.PER_CHAIN_STEPS
+    q0 = rs.standard_normal((D, N))
+    qd = as_device(q0, 0, np.float64)
+    qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
+    ro, rj, so = empty((N,), np.float64, 0), empty((N,), np.uint8, 0), empty((N,), np.int32, 0)
+    if rng == "upload":
+        p0 = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+        u = rs.uniform(size=N)
+        steps_in = rs.randint(1, L + 1, size=N).astype(np.int32)
+        pd, ud, sd = as_device(p0, 0, np.float64), as_device(u, 0, np.float64), torch.tensor(steps_in, device="cuda")
+        lib.call("pbbi_hmc_iter_dyn", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+                 md.data_ptr() if mass else None, sd.data_ptr(), qo.data_ptr(), po.data_ptr(), ro.data_ptr(),
+                 rj.data_ptr(), so.data_ptr(), N, N, h, L, flags, 1.0, stream_ptr(0))
+    else:
+        p0 = device_normal(lib, seed, lib.STREAM_MOMENTUM, 0, 0, D, N, 1.0, np.sqrt(m) if mass else None)
+        u = device_uniform(lib, seed, 0, 0, N)
+        steps_in = orc.philox_steps(seed, 0, 0, N, L)
+        lib.call("pbbi_hmc_run_dyn", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, qo.data_ptr(),
+                 po.data_ptr(), rj.data_ptr(), ro.data_ptr(), so.data_ptr(), N, N, h, L, 1, flags, seed, 0, 0, 1.0,
+                 stream_ptr(0))
+        dsteps = empty((N,), np.int32, 0)
+        lib.call("pbbi_philox_steps", seed, 0, 0, N, L, 0, dsteps.data_ptr(), stream_ptr(0))
+        assert np.array_equal(to_numpy(dsteps), steps_in)         # integer draw: device == oracle
+    torch.cuda.synchronize()
+    q_or, p_or = q0.copy(), p0.copy()
+    r_or, rej_or, st_or = orc.hmc_iter_dyn(op, q_or, p_or, u, m, h, L, steps_in=steps_in)
+    assert np.array_equal(to_numpy(so), st_or) and len(np.unique(st_or)) == L
+    assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
+    assert scaled_err(to_numpy(qo), q_or) <= RTOL_DENSE and scaled_err(to_numpy(po), p_or) <= RTOL_DENSE
+    with pytest.raises(lib.PbbiError):
+        lib.call("pbbi_hmc_run_dyn", pot.handle, 0, qd.data_ptr(), None, qo.data_ptr(), po.data_ptr(), rj.data_ptr(),
+                 ro.data_ptr(), so.data_ptr(), N, N, h, L, 1, flags | lib.UTURN_STOP, seed, 0, 0, 1.0, stream_ptr(0))
+
+
+def test_per_chain_steps_sampling_and_uturn_adaptation(P):
+    """getSamples(per_chain_steps=True) is a valid sampler (lengths are drawn independently of the state):
+    it recovers mean and variance of a Gaussian INCLUDING the coordinate a fixed length leaves unmixed
+    (omega*T = 2 pi), and adaptTrajectoryLength sets a length near the ensemble's U-turn time (about a
+    quarter to half a period of the slowest mode)."""
+    D, N = 4, 16384
+    prec = np.array([1.0, 4.0, (2 * np.pi) ** 2 / 4.0, 0.25])   # dimension 2: omega * T = 2 pi at T = 2
+    mu = np.array([0.5, -1.0, 2.0, 0.0])
+    pot = P.GaussianDiag(mu, prec=prec, const=0.0)
+    hmc = P.HMC(P.Ensemble(D, N), 2.0, 0.05, None, potential=pot, rng="philox", seed=1, verbose=False, kdk_fma=False)
+    s, _ = hmc.getSamples(60, 1.0 / kB, 1.0, per_chain_steps=True)
+    assert hmc.steps.shape == (60, N) and hmc.steps.min() == 1 and hmc.steps.max() == 40
+    x = s[:, :, 20:].reshape(D, -1)
+    assert np.max(np.abs(x.mean(1) - mu)) < 0.02
+    assert np.max(np.abs(x.var(1) * prec - 1.0)) < 0.05
+    T = hmc.adaptTrajectoryLength(1.0 / kB, 1.0, iterations=12, max_steps=400)
+    assert hmc.integrator.numSteps == int(round(T / 0.05)) and hmc.uturn_steps.shape == (6, N)
+    # slowest mode omega = 0.5: its U-turn comes after ~ a quarter period (pi) when started at the mode's
+    # edge, later otherwise; faster modes pull the multivariate criterion earlier
+    assert 0.5 < T < 2 * np.pi, T
