@@ -81,19 +81,34 @@ struct MmaF32 {
     }
     __device__ __forceinline__ void tile(const float* As, const float* Bs, int wm, int wn, int lane) {
         const int r = lane & 31, kh = lane >> 5;
+        // Software-pipelined by hand: the operands of K-step s+1 are read from LDS BEFORE the four
+        // MFMAs of K-step s issue, and the sched_barrier pins that order (left alone, hipcc emits
+        // read, s_waitcnt lgkmcnt(0), 4 MFMAs per step: every step then waits out an LDS round trip
+        // that only the previous step's last MFMA covers).
+        const float* ap = As + kh * BM + wm + r;
+        const float* bp = Bs + kh * BN + wn + r;
+        float a[2][2], b[2][2];
 #pragma unroll
-        for (int kk = 0; kk < Cfg<float>::BK; kk += 2) {
-            float a[2], b[2];
+        for (int t = 0; t < 2; ++t) {
+            a[0][t] = ap[32 * t];  // A[i = r][k = kh]
+            b[0][t] = bp[32 * t];  // B[k = kh][n = r]
+        }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = As[(kk + kh) * BM + wm + 32 * t + r];  // A[i = r][k = kh]
-                b[t] = Bs[(kk + kh) * BN + wn + 32 * t + r];  // B[k = kh][n = r]
+        for (int s = 0; s < Cfg<float>::BK / 2; ++s) {
+            const int c = s & 1, nx = c ^ 1;
+            if (s + 1 < Cfg<float>::BK / 2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[nx][t] = ap[2 * (s + 1) * BM + 32 * t];
+                    b[nx][t] = bp[2 * (s + 1) * BN + 32 * t];
+                }
             }
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][ta], b[c][tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // visit(i, n, tb, value): C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -234,15 +249,55 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
     typename MmaOf<T>::type mma;
     mma.zero();
     const int nk = prm.DPAD / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) load_tiles((t + 1) * BK);  // global loads in flight under the MFMAs
-        mma.tile(As[cur], Bs[cur], wm, wn, lane);
-        if (t + 1 < nk) store_tiles(cur ^ 1);
+    // Interior fp32 blocks with a zero mean (config C5's every block) fetch their operand tiles by
+    // LDS-DMA (buffer_load_dwordx4 ... lds): a tile row is 512 contiguous bytes in HBM and in LDS
+    // alike, one wave instruction moves two rows, no VGPR staging, no ds_write (8 x ds_write_b128 per
+    // thread and tile went through the LDS store path, which is shared by the CU and not hidden by
+    // MFMAs), no vmcnt wait in the middle of the MFMA stream.  PMC before: matrix pipe 77 % busy at
+    // 2.39 GHz (the clock was not the limit).
+    bool dma = false;
+    if constexpr (sizeof(T) == 4 && ZMEAN) {
+        dma = cols_full && prm.DPAD == prm.D && (reinterpret_cast<uintptr_t>(prm.PT) & 15) == 0 &&
+              (int64_t)prm.DPAD * (prm.ldq > prm.DPAD ? prm.ldq : prm.DPAD) * 4 < ((int64_t)1 << 32);
+    }
+    if (dma) {  // block-uniform
+        typedef __attribute__((address_space(3))) void lds_void;
+        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pa0), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pb0), 0, 0xFFFFFFF0u, 0x00020000);
+        const uint32_t half = (uint32_t)(lane >> 5), x16 = 16u * (uint32_t)(lane & 31);
+        const uint32_t vA = half * (uint32_t)prm.DPAD * 4u + x16, vB = half * (uint32_t)prm.ldq * 4u + x16;
+        auto dma_tiles = [&](int k0, int buf) {
+#pragma unroll
+            for (int j = 0; j < BK / 2 / (NTHR / 64); ++j) {  // wave w: row pairs w, w + 4, ...
+                const int pr = wave + (NTHR / 64) * j;
+                const uint32_t row = (uint32_t)(k0 + 2 * pr);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)&As[buf][2 * pr * BM], 16, vA,
+                                                         row * (uint32_t)prm.DPAD * 4u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)&Bs[buf][2 * pr * BN], 16, vB,
+                                                         row * (uint32_t)prm.ldq * 4u, 0, 0);
+            }
+        };
+        dma_tiles(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) dma_tiles((t + 1) * BK, cur ^ 1);  // lands under the MFMAs
+            mma.tile(As[cur], Bs[cur], wm, wn, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        load_tiles(0);
+        store_tiles(0);
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) load_tiles((t + 1) * BK);  // global loads in flight under the MFMAs
+            mma.tile(As[cur], Bs[cur], wm, wn, lane);
+            if (t + 1 < nk) store_tiles(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue, fp32 interior tiles: staged through LDS
