@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (tools/run_profiles_r02.sh) -> profiles/<tag>_kernel_stats.csv,
+profiles/<tag>_pmc.json (C2: k_dense_hmc, with the FETCH_SIZE calibration on k_dense_eval described in
+tools/profile_workload.py), profiles/<tag>_pmc_c3.json (k_ros2_hmc: one launch = 16 fused iterations),
+profiles/<tag>_pmc_c5.json (k_big_gemm)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.join(root, "gpurun_out", "prof_" + tag)
+P = os.path.join(root, "profiles")
+os.makedirs(P, exist_ok=True)
+newest = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)
+shutil.copy(newest(os.path.join(R, "kt", "**", "*_kernel_stats.csv")), os.path.join(P, f"{tag}_kernel_stats.csv"))
+
+
+def counters(w, kernels):
+    out = {}
+    for kind in ("sq", "fetch", "write"):
+        f = newest(os.path.join(R, f"pmc_{kind}_{w}", "**", "*_counter_collection.csv"))
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            for name in kernels:
+                if name in r["Kernel_Name"]:
+                    agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for name, cs in agg.items():
+            for c, v in cs.items():
+                out.setdefault(name, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+    return out
+
+
+# ---- C2
+out = counters("workload", ["k_dense_hmc", "k_dense_eval"])
+D, N = 128, 65536
+ev, hm = out.get("k_dense_eval", {}), out.get("k_dense_hmc", {})
+cal = {}
+if "FETCH_SIZE" in ev:
+    cal["fetch_kb_to_bytes"] = D * N * 8 / ev["FETCH_SIZE"]["mean_per_launch"]
+    cal["note"] = ("FETCH_SIZE factor = known bytes read by k_dense_eval (D*N*8) / its FETCH_SIZE: 1024 x the "
+                   "gfx950 under-count correction for this 8-B-per-lane access pattern")
+if "FETCH_SIZE" in hm and "WRITE_SIZE" in hm:
+    rd = hm["FETCH_SIZE"]["mean_per_launch"] * cal.get("fetch_kb_to_bytes", 2048.0)
+    wr = hm["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+    cal.update(k_dense_hmc_read_bytes_per_launch=rd, k_dense_hmc_write_bytes_per_launch=wr,
+               k_dense_hmc_hbm_bytes_per_launch=rd + wr, algorithmic_bytes_per_launch=(4 * D * 8 + 9) * N)
+if "GRBM_GUI_ACTIVE" in hm:
+    cyc = hm["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+    cal["k_dense_hmc_cycles_per_launch"] = cyc
+    cal["k_dense_hmc_mfma_busy_frac"] = hm["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (1024 * cyc)
+out["derived"] = cal
+json.dump(out, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
+print("C2", json.dumps(cal, indent=1))
+
+# ---- C3: one launch = 16 fused iterations
+out = counters("c3", ["k_ros2_hmc"])
+k = out.get("k_ros2_hmc", {})
+der = {"iterations_per_launch": 16}
+if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+    # q is read once per LAUNCH (8 B per lane: the factor calibrated above), samples are written every iteration
+    rd = k["FETCH_SIZE"]["mean_per_launch"] * cal.get("fetch_kb_to_bytes", 2048.0)
+    wr = k["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+    der.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=(rd + wr) / 16,
+               hbm_bytes_per_fused_launch=rd + wr, algorithmic_bytes_per_iteration=(4 * 32 * 8 + 9) * 262144)
+    der["note"] = "hbm_bytes_per_launch is per ITERATION (what bench.py's roofline.traffic is compared with)"
+if "SQ_WAIT_INST_ANY" in k:
+    der["wait_inst_any_over_active_valu"] = (k["SQ_WAIT_INST_ANY"]["mean_per_launch"] /
+                                             k["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
+    der["valu_instructions_per_wave_iteration"] = k["SQ_INSTS_VALU"]["mean_per_launch"] / 8192 / 16
+    der["cycles_per_launch"] = k["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+out["derived"] = der
+json.dump(out, open(os.path.join(P, f"{tag}_pmc_c3.json"), "w"), indent=1)
+print("C3", json.dumps(der, indent=1))
+
+# ---- C5
+out = counters("c5", ["k_big_gemm"])
+k = out.get("k_big_gemm", {})
+der = {}
+if "GRBM_GUI_ACTIVE" in k:
+    cyc = k["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+    mfma = 2.0 * 4096 * 4096 * 8192 / 4096        # v_mfma_f32_32x32x2 = 4096 flop, 64 cycles on its SIMD
+    der.update(cycles_per_launch=cyc, mfma_instructions_per_launch=mfma,
+               mfma_busy_frac_from_count=mfma * 64 / (1024 * cyc),
+               note="SQ_VALU_MFMA_BUSY_CYCLES saturates at 2^32 on this kernel: busy = MFMA count x 64 cycles / (1024 SIMDs x cycles)")
+if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+    der["fetch_bytes_per_launch_x2"] = k["FETCH_SIZE"]["mean_per_launch"] * 2048.0
+    der["write_bytes_per_launch"] = k["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+out["derived"] = der
+json.dump(out, open(os.path.join(P, f"{tag}_pmc_c5.json"), "w"), indent=1)
+print("C5", json.dumps(der, indent=1))
+print(open(os.path.join(P, f"{tag}_kernel_stats.csv")).read()[:1500])
