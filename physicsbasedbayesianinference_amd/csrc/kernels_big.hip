@@ -26,6 +26,7 @@
 //
 // Stormer-Verlet runs on the same epilogue: no closing half kick, one more drift, and one
 // evaluation GEMM for U of the final position.
+#include <cstdlib>
 #include <vector>
 
 #include "pbbi_internal.h"
@@ -65,6 +66,7 @@ struct GemmPrm {
     int64_t N, ldq, ldw, ldg;
     int D, DPAD;
     T hk, h;
+    int no_dma;  // PBBI_BIG_NO_DMA=1: A/B switch for profiling (register-staged tiles everywhere)
 };
 
 // ---- per-wave MFMA micro-kernels ---------------------------------------------------------------
@@ -135,18 +137,29 @@ struct MmaF64 {  // 64 x 32 per wave: 4 x 2 tiles of 16 x 16
     }
     __device__ __forceinline__ void tile(const double* As, const double* Bs, int wm, int wn, int lane) {
         const int r = lane & 15, kq = lane >> 4;
+        // operands of K-step s+1 are read before the eight MFMAs of K-step s issue (see MmaF32::tile)
+        const double* ap = As + kq * BM + wm + r;
+        const double* bp = Bs + kq * BN + wn + r;
+        double a[2][4], b[2][2];
 #pragma unroll
-        for (int kk = 0; kk < Cfg<double>::BK; kk += 4) {
-            double a[4], b[2];
+        for (int t = 0; t < 4; ++t) a[0][t] = ap[16 * t];  // A[i = r][k = kq]
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = As[(kk + kq) * BM + wm + 16 * t + r];  // A[i = r][k = kq]
+        for (int t = 0; t < 2; ++t) b[0][t] = bp[16 * t];  // B[k = kq][n = r]
 #pragma unroll
-            for (int t = 0; t < 2; ++t) b[t] = Bs[(kk + kq) * BN + wn + 16 * t + r];  // B[k = kq][n = r]
+        for (int s = 0; s < Cfg<double>::BK / 4; ++s) {
+            const int c = s & 1, nx = c ^ 1;
+            if (s + 1 < Cfg<double>::BK / 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[nx][t] = ap[4 * (s + 1) * BM + 16 * t];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) b[nx][t] = bp[4 * (s + 1) * BN + 16 * t];
+            }
 #pragma unroll
             for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][ta], b[c][tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
@@ -249,32 +262,36 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
     typename MmaOf<T>::type mma;
     mma.zero();
     const int nk = prm.DPAD / BK;
-    // Interior fp32 blocks with a zero mean (config C5's every block) fetch their operand tiles by
+    // Interior blocks with a zero mean (config C5's every block) fetch their operand tiles by
     // LDS-DMA (buffer_load_dwordx4 ... lds): a tile row is 512 contiguous bytes in HBM and in LDS
     // alike, one wave instruction moves two rows, no VGPR staging, no ds_write (8 x ds_write_b128 per
     // thread and tile went through the LDS store path, which is shared by the CU and not hidden by
     // MFMAs), no vmcnt wait in the middle of the MFMA stream.  PMC before: matrix pipe 77 % busy at
     // 2.39 GHz (the clock was not the limit).
     bool dma = false;
-    if constexpr (sizeof(T) == 4 && ZMEAN) {
-        dma = cols_full && prm.DPAD == prm.D && (reinterpret_cast<uintptr_t>(prm.PT) & 15) == 0 &&
-              (int64_t)prm.DPAD * (prm.ldq > prm.DPAD ? prm.ldq : prm.DPAD) * 4 < ((int64_t)1 << 32);
+    if constexpr (ZMEAN) {
+        dma = !prm.no_dma && cols_full && prm.DPAD == prm.D && (reinterpret_cast<uintptr_t>(prm.PT) & 15) == 0 &&
+              (int64_t)prm.DPAD * (prm.ldq > prm.DPAD ? prm.ldq : prm.DPAD) * (int64_t)sizeof(T) < ((int64_t)1 << 32);
     }
     if (dma) {  // block-uniform
         typedef __attribute__((address_space(3))) void lds_void;
         const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pa0), 0, 0xFFFFFFF0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pb0), 0, 0xFFFFFFF0u, 0x00020000);
-        const uint32_t half = (uint32_t)(lane >> 5), x16 = 16u * (uint32_t)(lane & 31);
-        const uint32_t vA = half * (uint32_t)prm.DPAD * 4u + x16, vB = half * (uint32_t)prm.ldq * 4u + x16;
+        // one wave instruction = 1 KiB = RPI tile rows (2 of 512 B in fp32, 1 of 1 KiB in fp64)
+        constexpr int LPR = BM * (int)sizeof(T) / 16;  // lanes per tile row
+        constexpr int RPI = 64 / LPR;                  // rows per instruction
+        constexpr uint32_t ES = (uint32_t)sizeof(T);
+        const uint32_t sub = (uint32_t)(lane / LPR), x16 = 16u * (uint32_t)(lane % LPR);
+        const uint32_t vA = sub * (uint32_t)prm.DPAD * ES + x16, vB = sub * (uint32_t)prm.ldq * ES + x16;
         auto dma_tiles = [&](int k0, int buf) {
 #pragma unroll
-            for (int j = 0; j < BK / 2 / (NTHR / 64); ++j) {  // wave w: row pairs w, w + 4, ...
+            for (int j = 0; j < BK / RPI / (NTHR / 64); ++j) {  // wave w: row groups w, w + NWAVES, ...
                 const int pr = wave + (NTHR / 64) * j;
-                const uint32_t row = (uint32_t)(k0 + 2 * pr);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)&As[buf][2 * pr * BM], 16, vA,
-                                                         row * (uint32_t)prm.DPAD * 4u, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)&Bs[buf][2 * pr * BN], 16, vB,
-                                                         row * (uint32_t)prm.ldq * 4u, 0, 0);
+                const uint32_t row = (uint32_t)(k0 + RPI * pr);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)&As[buf][RPI * pr * BM], 16, vA,
+                                                         row * (uint32_t)prm.DPAD * ES, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)&Bs[buf][RPI * pr * BN], 16, vB,
+                                                         row * (uint32_t)prm.ldq * ES, 0, 0);
             }
         };
         dma_tiles(0, 0);
@@ -602,7 +619,9 @@ template <typename T>
 int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next, T* vh, int64_t ldw,
          const T* minv, T* grad_out, int64_t ldg, T* xg_part, int64_t N, T hk, T h, hipStream_t st) {
     GemmPrm<T> prm{(const T*)pot->d_big_PT, (const T*)pot->d_big_mu, q, q_next, vh, minv, grad_out,
-                   xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h};
+                   xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h, 0};
+    static const bool no_dma = (getenv("PBBI_BIG_NO_DMA") != nullptr);
+    prm.no_dma = no_dma ? 1 : 0;
     const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
     size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
     if (sizeof(T) == 4) {  // the staged fp32 epilogue: [BM][BN+4] tile + [NTHR/32][BN] partial sums
