@@ -44,8 +44,14 @@ constexpr int BM = 128, BN = 128;
 // (328 registers: 0.27-0.47 of the fp64 MFMA peak at D = 256...1024); with 8 waves (2 x 4), 64 x 32
 // per wave, it fits 128 registers: two workgroups per CU, four waves per SIMD.
 template <typename T> struct Cfg;
+#ifndef PBBI_BIG_F32_BK
+#define PBBI_BIG_F32_BK 32
+#endif
+#ifndef PBBI_BIG_F32_MINW
+#define PBBI_BIG_F32_MINW 2
+#endif
 template <> struct Cfg<float> {
-    static constexpr int BK = 32, NTHR = 256, WAVES_N = 2, WTN = 64, MIN_WAVES = 2;
+    static constexpr int BK = PBBI_BIG_F32_BK, NTHR = 256, WAVES_N = 2, WTN = 64, MIN_WAVES = PBBI_BIG_F32_MINW;
 };
 template <> struct Cfg<double> {
     static constexpr int BK = 16, NTHR = 512, WAVES_N = 4, WTN = 32, MIN_WAVES = 4;
@@ -330,6 +336,9 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
         constexpr int RGS = NTHR / 32;  // row groups
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         bool staged = (i0 + BM <= prm.D) && (n0 + BN <= prm.N) && q_vec_ok;
+#ifdef PBBI_BIG_NO_STAGED
+        staged = false;
+#endif
         if constexpr (EPI == EPI_EVAL)
             staged = staged && (!prm.grad_out || (prm.ldg % 4 == 0 && al16(prm.grad_out)));
         else
@@ -624,10 +633,12 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
     prm.no_dma = no_dma ? 1 : 0;
     const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
     size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
+#ifndef PBBI_BIG_NO_STAGED
     if (sizeof(T) == 4) {  // the staged fp32 epilogue: [BM][BN+4] tile + [NTHR/32][BN] partial sums
         const size_t staged = (size_t)BM * (BN + 4) * sizeof(T) + (size_t)(Cfg<T>::NTHR / 32) * BN * sizeof(T);
         if (staged > lds) lds = staged;
     }
+#endif
     auto go = [&](auto kernel) -> int {
         PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -673,7 +673,13 @@ inline bool streams(const pbbi_potential* pot) { return pot->dtype != PBBI_F64 |
 }  // namespace
 
 int lane_hmc_iter(const IterArgs& a) {
-    if (pbbi_dyn(a)) return lane_dyn_hmc_iter(a);
+    if (pbbi_dyn(a)) {  // per-chain trajectory lengths: the two-lane Rosenbrock kernel or k_lane_dyn_hmc
+        static const bool no_lane2_dyn = (getenv("PBBI_NO_LANE2") != nullptr);
+        if (!no_lane2_dyn && lane2_applies(a) && !streams(a.pot) && a.N > 0 &&
+            check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) == PBBI_OK)
+            return lane2_hmc_iter(a);
+        return lane_dyn_hmc_iter(a);
+    }
     if (sepn_applies(a)) return sepn_hmc_iter(a);
     if (rosg_applies(a)) return rosg_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 32 < D <= 128: 4 / 8 lanes of one wave
     if (rosn_applies(a)) return rosn_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 128 < D <= 256: parts in waves  // PBBI_KDK_FMA, separable, 16 < D <= 256

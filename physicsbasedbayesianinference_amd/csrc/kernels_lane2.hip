@@ -213,9 +213,15 @@ __device__ __forceinline__ double pp_pair(const double (&p)[DL]) {
 // One HMC iteration of the wave's 32 chains once their positions are in q[]: momentum (drawn or
 // uploaded), H_old, the trajectory, H_new, the decision and the stores (src/HMC.py:154-179).
 // n0 = first chain of the tile (wave-uniform), c = chain within the tile, half = which 16 dims.
-template <bool UNIT, bool FULL, bool KDK>
+// DYN (PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP, reference-order form only): the chain's own step count
+// and the stop at (q_j - q_0) . v_j < 0.  Both lanes of a chain take the same decision (the dot product
+// is summed in dimension order across the halves, like the energies: bit-exact with the oracle's
+// leapfrog_chain_dyn), so they stay paired for the q_16 / carry exchanges inside the masked loop.
+template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
 __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& pot, int64_t n0, int c,
-                                          int half, bool valid, int cc, double (&q)[DL]) {
+                                          int half, bool valid, int cc, double (&q)[DL],
+                                          const int32_t* steps_in = nullptr, int32_t* steps_out = nullptr) {
+    static_assert(!(KDK && DYN), "per-chain lengths run in the reference-order form");
     const int D = prm.D;
     const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
     const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
@@ -232,6 +238,7 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     auto exists = [&](int j) { return pot.exists(j); };
 
     double v[DL], a[DL];  // v holds p, then the velocity, then p again
+    [[maybe_unused]] int steps = 0;  // DYN: leapfrog steps this chain took
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
     auto draw = [&]() {
 #pragma unroll
@@ -275,6 +282,43 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
 #pragma unroll
                 for (int j = 0; j < DL; ++j) q[j] = fma(v[j], h, q[j]);
                 pot.kdk_kick(q, v, (s + 1 < prm.L) ? hm : hhm);
+            }
+        }
+    } else if constexpr (DYN) {
+        int Ln = prm.L;
+        if (prm.flags & PBBI_PER_CHAIN_STEPS) {
+            if (prm.rng) Ln = prm.L > 0 ? rng_steps(prm.seed, prm.iter, chain, prm.L) : 0;
+            else if (steps_in) Ln = steps_in[n0 + cc];
+            Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
+        }
+        const bool uturn = (prm.flags & PBBI_UTURN_STOP) != 0;
+        double q0[DL];
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q0[j] = q[j];
+        pot.neg_grad_each(q, [&](int j, double ng) { a[j] = UNIT ? ng : ng / m; });
+        bool active = Ln > 0;
+        while (__builtin_amdgcn_ballot_w64(active) != 0) {  // until the wave's last chain has stopped
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < DL; ++j) q[j] += (v[j] * h + a[j] * hh2);
+                pot.neg_grad_each(q, [&](int j, double ng) {
+                    const double an = UNIT ? ng : ng / m;
+                    v[j] += (a[j] + an) * hh;
+                    a[j] = an;
+                });
+                ++steps;
+                // (q - q0) . v summed over the 32 dimensions in order: half 1 continues half 0's sum
+                double dot = 0.0;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    double r = pass ? xchg(dot) : 0.0;
+#pragma unroll
+                    for (int j = 0; j < DL; ++j) r += (q[j] - q0[j]) * v[j];
+                    if (pass == 0 || half) dot = r;
+                }
+                const double other = xchg(dot);
+                if (!half) dot = other;  // both lanes hold the chain's sum
+                active = steps < Ln && !(uturn && dot < 0.0);
             }
         }
     } else {
@@ -333,6 +377,9 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
         if (half == 0) {
             if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
             if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+            if constexpr (DYN) {
+                if (steps_out) steps_out[n0 + c] = steps;
+            }
         }
     }
     RSTAMP(n0 / CHAINS_PER_BLOCK, 4);
@@ -356,6 +403,8 @@ struct Ros2Run {
     int64_t slab0;    // index of the first iteration's position slab
     int64_t slab;     // elements per slab (D * N)
     double* q_base;   // slab 0 of the position slabs
+    const int32_t* steps_in;  // DYN instantiation only: PBBI_PER_CHAIN_STEPS with uploaded draws (nullptr: L)
+    int32_t* steps_out;       // DYN instantiation only: the steps each chain took
 };
 
 // One 32-chain tile per one-wave workgroup; the chain stays in registers for run.S consecutive HMC
@@ -366,7 +415,7 @@ struct Ros2Run {
 // a wave pays the load once per launch, only samples leave the chip, and waves that share a SIMD
 // drift out of step within a few iterations, so that one wave's draw (32-bit multiplies, xors) and
 // stores run beside another's trajectory (fp64).
-template <bool UNIT, bool FULL, bool KDK>
+template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
 __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBBI_ROS2_WAVES_KDK - 1)
                                               : PBBI_ROS2_WAVES_EXACT)
     k_ros2_hmc(Ros2Prm prm, Ros2Run run) {
@@ -400,7 +449,8 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
         if (prm.ratio_out) it.ratio_out = prm.ratio_out + (int64_t)k * prm.N;
         if (prm.reject_out) it.reject_out = prm.reject_out + (int64_t)k * prm.N;
         it.iter = prm.iter + (uint64_t)k;
-        ros2_tile<UNIT, FULL, KDK>(it, pot, n0, c, half, valid, cc, q);
+        if constexpr (DYN) ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, run.steps_in, run.steps_out);
+        else ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q);
     }
 #ifdef PBBI_STAMPS_ROS2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,15 +481,21 @@ int lane2_hmc_iter(const IterArgs& a) {
                 (2.0 * pot->b) * (1.0 / pot->s), a.L, pot->D, a.flags, a.rng, a.seed, a.iter,
                 a.chain0};
     // a single iteration is a run of one whose only "slab" is q_out
-    Ros2Run run{1, 0, 0, (int64_t)pot->D * a.N, (double*)a.q_out};
-    if (a.fuse_S > 1) run = Ros2Run{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)pot->D * a.N, (double*)a.fuse_q_base};
+    Ros2Run run{1, 0, 0, (int64_t)pot->D * a.N, (double*)a.q_out, a.steps_in, a.steps_out};
+    if (a.fuse_S > 1)
+        run = Ros2Run{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)pot->D * a.N, (double*)a.fuse_q_base, nullptr, nullptr};
     const dim3 grid((unsigned)((a.N + CHAINS_PER_BLOCK - 1) / CHAINS_PER_BLOCK)), block(BLOCK);
     const bool full = (pot->D == 32);
-    const bool kdk = (a.flags & PBBI_KDK_FMA) != 0;
+    const bool dyn = pbbi_dyn(a);                                  // per-chain lengths: reference-order form
+    const bool kdk = !dyn && (a.flags & PBBI_KDK_FMA) != 0;
 #define ROS2_LAUNCH(U_, F_)                                                                          \
     {                                                                                                \
-        if (kdk) hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true>), grid, block, 0, a.stream, prm, run); \
-        else hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false>), grid, block, 0, a.stream, prm, run);    \
+        if (dyn)                                                                                     \
+            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false, true>), grid, block, 0, a.stream, prm, run); \
+        else if (kdk)                                                                                \
+            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true>), grid, block, 0, a.stream, prm, run);      \
+        else                                                                                         \
+            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false>), grid, block, 0, a.stream, prm, run);     \
     }
     if (a.mass) {
         if (full) ROS2_LAUNCH(false, true) else ROS2_LAUNCH(false, false)

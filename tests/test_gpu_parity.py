@@ -1712,6 +1712,8 @@ def _dyn_case(P, case, rs):
         return 12, P.Rosenbrock(12), orc.pot_rosenbrock(12), 0.03
     if case == "ros32":
         return 32, P.Rosenbrock(32), orc.pot_rosenbrock(32), 0.03
+    if case == "ros20":
+        return 20, P.Rosenbrock(20), orc.pot_rosenbrock(20), 0.03
     D = int(case[5:])
     A = rs.standard_normal((D, D))
     Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
@@ -1720,11 +1722,12 @@ def _dyn_case(P, case, rs):
 
 
 @pytest.mark.parametrize("case,mass", [("diag5", False), ("diag30", True), ("harm3", True), ("ros12", False),
-                                       ("ros32", True)])
+                                       ("ros32", True), ("ros32", False), ("ros20", True)])  # ros20/32: two-lane kernel
 @pytest.mark.parametrize("mode", ["steps", "uturn", "both"])
 def test_per_chain_steps_lane_kernels_bitexact(P, lib, case, mass, mode):
-    """pbbi_hmc_iter_dyn on the chain-per-lane kernels: per-chain step counts (uploaded) and / or the
-    U-turn stop, against the oracle's leapfrog_chain_dyn -- step counts, decisions, q and p bit for bit."""
+    """pbbi_hmc_iter_dyn on the chain-per-lane kernels (k_lane_dyn_hmc; Rosenbrock with 16 < D <= 32 on the
+    two-lane kernel's DYN instantiation): per-chain step counts (uploaded) and / or the U-turn stop,
+    against the oracle's leapfrog_chain_dyn -- step counts, decisions, q and p bit for bit."""
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     rs = np.random.RandomState(len(case) * 7 + len(mode))
