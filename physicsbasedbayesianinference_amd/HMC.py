@@ -64,6 +64,7 @@ class _HostDrawPipeline:
         self.side = t.cuda.Stream(device=dev(device))
         self.main = t.cuda.current_stream(dev(device))
         td = torch_dtype(np_dtype)
+        self.free = queue.Queue()   # slots the consumer has handed back (initially: all of them)
         self.slots = []
         for _ in range(min(depth, self.S)):
             s = self.Slot()
@@ -74,6 +75,7 @@ class _HostDrawPipeline:
             s.uploaded = t.cuda.Event()
             s.consumed = None
             self.slots.append(s)
+            self.free.put(s)
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
 
@@ -84,12 +86,16 @@ class _HostDrawPipeline:
             for i in range(self.S):
                 if self.stop:  # the consumer gave up (an error in a launch): leave the rest of the stream undrawn
                     return
-                s = self.slots[i % len(self.slots)]
                 t0 = time.perf_counter()
                 p, u = self.draw(i)
                 self.draw_seconds += time.perf_counter() - t0
+                # a slot is reused only after the consumer has LAUNCHED the kernel that reads it (it comes
+                # back through `free`) and that kernel has finished (its event)
+                s = self.free.get()
+                if s is None or self.stop:
+                    return
                 if s.consumed is not None:
-                    s.consumed.synchronize()   # the kernel that read this slot's device buffers is done
+                    s.consumed.synchronize()
                 s.pin_p.copy_(t.from_numpy(np.ascontiguousarray(p)))   # also converts float64 -> the handle's dtype
                 s.pin_u.copy_(t.from_numpy(np.ascontiguousarray(u)))
                 with t.cuda.stream(self.side):
@@ -111,10 +117,12 @@ class _HostDrawPipeline:
     def release(self, s):
         s.consumed = self.t.cuda.Event()
         s.consumed.record(self.main)
+        self.free.put(s)
 
     def close(self):
         self.stop = True
         if self.thread is not None:
+            self.free.put(None)   # wakes a producer that waits for a slot
             self.thread.join()
 
 # adaptStepSize's Philox key = seed ^ this (the sampling run keeps `seed`)

@@ -17,6 +17,8 @@
 // Algebraically src/integrator.py:105-120; agrees with the oracle to ~1e-13 relative, accept masks
 // equal (tests/test_gpu_parity.py::test_separable_multilane_kdk).  The bit-exact reference-order
 // kernels stay the default; this path is taken only when the caller passes PBBI_KDK_FMA.
+#include <cstdlib>
+
 #include "pbbi_buf.h"
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
@@ -41,6 +43,7 @@ struct SepPrm {
     double h, cst, kT;
     int L, D, flags, rng;
     uint64_t seed, iter, chain0;
+    int harmonic;  // k_sep_exact_hmc: U = 0.5 sum k q^2 in the harmonic potential's own operation order
 };
 
 // FULL: D is a multiple of 16, every dim of every part exists: no guards (as scalar branches they
@@ -197,6 +200,157 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_sep_exact_hmc: the same parts-in-waves layout in the REFERENCE'S OPERATION ORDER (Leapfrog,
+// src/integrator.py:105-120, exactly as kernels_lane.hip::integrate_chain) -- the default of the drop-in
+// (PBBI_KDK_FMA not set).  State per lane q, v, a (96 VGPRs per 16 dims, four waves per SIMD); the
+// gradient of a separable potential is elementwise, so the trajectory needs nothing from the other
+// parts.  What ties the parts together is the ORDER of the two energy sums (p.p and the potential's
+// terms run over d = 0 .. D-1 in the oracle): part g continues part g-1's running sums through LDS, G
+// short dependent steps per Hamiltonian, and every wave reads the totals -> H, the ratio and the
+// decision have the oracle's bits, like q and p.  Before: one chain per lane up to D = 64 (0.44 / 0.24
+// of the HBM roofline at D = 32 / 64) and the workspace kernels beyond (0.04).
+// ------------------------------------------------------------------------------------------------
+template <bool UNIT, bool FULL>
+__global__ void __launch_bounds__(64 * MAXG) k_sep_exact_hmc(SepPrm prm) {
+    __shared__ double run_pp[64], run_u[64];
+    const int c = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
+    const int G = (int)(blockDim.x >> 6);
+    const int64_t n0 = (int64_t)blockIdx.x * 64;  // block-uniform
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;
+    const int D = prm.D;
+    const int d0 = DL * part;
+    const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
+    const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vo = 8u * (uint32_t)cc;
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
+    auto exists = [&](int j) { return FULL || d0 + j < D; };  // wave-uniform
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) { return buf_load<double>(r, vo, (uint32_t)j * rin); };
+    auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) { buf_store(r, vo, (uint32_t)j * rout, x); };
+
+    // this part's constants (SGPRs); the parameter vectors are zero-padded: a dim past D has prec = 0,
+    // mean = 0 and q = v = a = 0 throughout, its terms add exact zeros
+    double mu[DL], pr[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        mu[j] = prm.mean[d0 + j];
+        pr[j] = prm.prec[d0 + j];
+    }
+    double q[DL], v[DL], a[DL];  // v holds p, then the velocity, then p again
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        const double x = ld(bq, j);
+        q[j] = exists(j) ? x : 0.0;
+    }
+    const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    auto draw = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+        }
+    };
+    auto load_p = [&]() {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double x = ld(bp, j);
+            v[j] = exists(j) ? x : 0.0;
+        }
+    };
+    if (prm.rng) draw(); else load_p();
+
+    // H = 0.5 p.p / m + (0.5 acc + cst), both sums in dimension order across the parts
+    // (src/HMC.py:100-102; oracle pot_U): part g starts from part g-1's running sums
+    auto hamiltonian = [&]() {
+        for (int g = 0; g < G; ++g) {
+            if (part == g) {
+                double pp = g ? run_pp[c] : 0.0, acc = g ? run_u[c] : 0.0;
+#pragma unroll
+                for (int j = 0; j < DL; ++j) pp += v[j] * v[j];
+                if (prm.harmonic) {
+#pragma unroll
+                    for (int j = 0; j < DL; ++j) acc += pr[j] * (q[j] * q[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DL; ++j) {
+                        const double x = q[j] - mu[j];
+                        acc += (pr[j] * x) * x;
+                    }
+                }
+                run_pp[c] = pp;
+                run_u[c] = acc;
+            }
+            __syncthreads();
+        }
+        const double H = 0.5 * run_pp[c] / m + (0.5 * run_u[c] + prm.cst);
+        __syncthreads();  // everyone has read the totals before the next Hamiltonian overwrites them
+        return H;
+    };
+    const double oldH = hamiltonian();
+
+    // ---- Leapfrog.integrate, src/integrator.py:105-120 (operation order of integrate_chain)
+    const double h = prm.h, hh2 = 0.5 * (prm.h * prm.h), hh = 0.5 * prm.h;
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        if constexpr (!UNIT) v[j] = v[j] / m;
+        const double g = pr[j] * (q[j] - mu[j]);
+        a[j] = UNIT ? -g : -g / m;
+    }
+    for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            q[j] += (v[j] * h + a[j] * hh2);
+            const double g = pr[j] * (q[j] - mu[j]);
+            const double an = UNIT ? -g : -g / m;
+            v[j] += (a[j] + an) * hh;
+            a[j] = an;
+        }
+    }
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+    const double newH = hamiltonian();
+    const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
+    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] = ld(bq, j);  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < DL; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+                load_p();
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) st(bqo, j, q[j]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) st(bpo, j, v[j]);
+        }
+        if (part == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace
 
 // true if this path takes the call: harmonic / diagonal Gaussian, fp64, Leapfrog, 16 < D <= 256,
@@ -214,7 +368,8 @@ int sepn_hmc_iter(const IterArgs& a) {
     SepPrm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
                (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
                a.reject_out, (const double*)pot->d_mean, (const double*)pot->d_prec, a.N, a.ldn_in,
-               a.ldn_out, a.h, pot->cst, a.kT, a.L, pot->D, a.flags, a.rng, a.seed, a.iter, a.chain0};
+               a.ldn_out, a.h, pot->cst, a.kT, a.L, pot->D, a.flags, a.rng, a.seed, a.iter, a.chain0,
+               pot->kind == KIND_HARMONIC ? 1 : 0};
     const int G = (pot->D + DL - 1) / DL;
     const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
     const bool full = (pot->D % DL == 0);
@@ -231,6 +386,38 @@ int sepn_hmc_iter(const IterArgs& a) {
         if (full) SEP_LAUNCH(true, true) else SEP_LAUNCH(true, false)
     }
 #undef SEP_LAUNCH
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// the reference-order form of the same layout: harmonic / diagonal Gaussian, fp64, Leapfrog,
+// 16 < D <= 256, PBBI_KDK_FMA not set
+bool sepx_applies(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    static const bool off = (getenv("PBBI_NO_SEPX") != nullptr);  // A/B switch
+    return !off && (pot->kind == KIND_HARMONIC || pot->kind == KIND_GAUSS_DIAG) && pot->dtype == PBBI_F64 &&
+           a.method == PBBI_LEAPFROG && (a.flags & PBBI_KDK_FMA) == 0 && pot->D > 16 && pot->D <= DL * MAXG &&
+           (int64_t)DL * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
+}
+
+int sepx_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (a.N == 0) return PBBI_OK;
+    SepPrm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+               (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
+               a.reject_out, (const double*)pot->d_mean, (const double*)pot->d_prec, a.N, a.ldn_in,
+               a.ldn_out, a.h, pot->cst, a.kT, a.L, pot->D, a.flags, a.rng, a.seed, a.iter, a.chain0,
+               pot->kind == KIND_HARMONIC ? 1 : 0};
+    const int G = (pot->D + DL - 1) / DL;
+    const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
+    const bool full = (pot->D % DL == 0);
+    if (a.mass) {
+        if (full) hipLaunchKernelGGL((k_sep_exact_hmc<false, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_sep_exact_hmc<false, false>), grid, block, 0, a.stream, prm);
+    } else {
+        if (full) hipLaunchKernelGGL((k_sep_exact_hmc<true, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_sep_exact_hmc<true, false>), grid, block, 0, a.stream, prm);
+    }
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

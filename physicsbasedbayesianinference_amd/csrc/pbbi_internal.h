@@ -187,6 +187,9 @@ int lane_dyn_hmc_iter(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
 bool sepn_applies(const IterArgs& a);
 int sepn_hmc_iter(const IterArgs& a);
+// ... and in the reference's operation order (bit-exact), PBBI_KDK_FMA not set
+bool sepx_applies(const IterArgs& a);
+int sepx_hmc_iter(const IterArgs& a);
 // Rosenbrock, 32 < D <= 256, PBBI_KDK_FMA, same layout with boundary exchange through LDS, kernels_rosn.hip
 bool rosn_applies(const IterArgs& a);
 int rosn_hmc_iter(const IterArgs& a);

@@ -1828,3 +1828,61 @@ def test_per_chain_steps_sampling_and_uturn_adaptation(P):
     # slowest mode omega = 0.5: its U-turn comes after ~ a quarter period (pi) when started at the mode's
     # edge, later otherwise; faster modes pull the multivariate criterion earlier
     assert 0.5 < T < 2 * np.pi, T
+
+
+# ------------------------------------------------------------------ reference-order separable kernel, 16 < D <= 256
+@pytest.mark.parametrize("kind,D,N,mass,compat", [("diag", 17, 100, False, True), ("diag", 32, 700, True, False),
+                                                  ("harmonic", 48, 333, True, True), ("diag", 64, 130, False, True),
+                                                  ("diag", 100, 257, True, True), ("harmonic", 128, 64, False, False),
+                                                  ("diag", 250, 70, True, True), ("diag", 256, 129, False, True)])
+@pytest.mark.parametrize("rng", ["upload", "philox"])
+def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, compat, rng):
+    """k_sep_exact_hmc (kernels_sepn.hip): 16-dim parts of a chain in the waves of a workgroup, the
+    reference's operation order, energy sums continued from part to part -> q, p, ratio's decision
+    BIT-EXACT with the oracle for harmonic / diagonal Gaussian potentials up to D = 256, the path the
+    drop-in's default (kdk_fma=False) takes; forced rejections, masses, both momentum-restore conventions."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D + N)
+    if kind == "diag":
+        mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2.0, D)
+        pot, op = P.GaussianDiag(mu, prec=prec, const=0.3), orc.pot_gauss_diag(mu, prec, 0.3)
+    else:
+        k = rs.uniform(0.5, 2.0, D)
+        pot, op = P.Harmonic(k), orc.pot_harmonic(k)
+    h, L, S, seed, chain0 = 0.3, 7, 3, 5, 1000
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    flags = lib.COMPAT_P_FROM_OLDQ if compat else 0
+    st = stream_ptr(0)
+    q = np.ascontiguousarray(rs.standard_normal((D, N)))
+    n_rej = 0
+    if rng == "upload":
+        for it in range(S):
+            p = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+            u = rs.uniform(size=N)
+            u[::4] = 1.5
+            qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, m, h, L, compat=compat)
+            q_or, p_or = q.copy(), p.copy()
+            r_or, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L, compat=flags)
+            assert np.array_equal(rej, rej_or)
+            assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
+            fin = np.isfinite(r_or) & (r_or > 0)
+            assert np.max(np.abs(np.log(ratio[fin]) - np.log(r_or[fin]))) < 1e-9
+            n_rej += int(rej.sum())
+            q = qo
+        assert n_rej >= S * (N // 4)
+    else:
+        qd = as_device(q, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject = empty((S, N), np.uint8, 0)
+        lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, samples.data_ptr(),
+                 momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, seed, 0, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        pstd = np.sqrt(m) if mass else None
+        for i in range(S):
+            p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, chain0, D, N, 1.0, pstd)
+            u = device_uniform(lib, seed, i, chain0, N)
+            _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=flags)
+            assert np.array_equal(to_numpy(reject[i]).astype(bool), rej)
+            assert np.array_equal(to_numpy(samples[i]), q) and np.array_equal(to_numpy(momenta[i]), p)
