@@ -4,8 +4,10 @@
 // flop per step*chain), but with one chain per lane its q, v, a (192 VGPRs at D = 32) leave room
 // for only ONE wave per SIMD, so every wave's load, compute and store phases coincide and
 // nothing overlaps (measured: 22-28 % of the HBM roofline, time = memory time + VALU time).
-// Here lanes l and l^32 share a chain and hold 16 dims each (96 VGPRs of state): three waves
-// per SIMD fit, and one wave's HBM phase hides under the others' arithmetic.
+// Here lanes l and l^32 share a chain and hold 16 dims each (96 VGPRs of state in the reference
+// order, 64 in the kick-drift-kick form): two / four waves per SIMD fit, one wave's HBM phase hides
+// under the others' arithmetic, and pbbi_hmc_run keeps the chain in these registers for several
+// iterations per launch (k_ros2_hmc below).
 //
 //   lane l: chain c = l & 31 of the wave's 32 chains, half = l >> 5, dims i = 16*half + j.
 //   Loads/stores: each half-wave touches 32 consecutive chains of one row = 256 contiguous bytes.
@@ -23,8 +25,8 @@
 
 namespace {
 
-constexpr int BLOCK = 64;            // one wave = 32 chains per workgroup: 8192 small workgroups at
-constexpr int CHAINS_PER_BLOCK = 32; // C3 balance the last dispatch round better than 2048 of 4 waves
+constexpr int BLOCK = 64;            // one wave = 32 chains per workgroup: C3's 8192 one-wave workgroups are
+constexpr int CHAINS_PER_BLOCK = 32; // exactly two rounds of the chip's 4096 slots (four waves per SIMD)
 constexpr int DL = 16;               // dims per lane
 
 struct Ros2Prm {

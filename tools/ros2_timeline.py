@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-wave timeline of k_ros2_hmc on config C3 from a diagnostic build (tools/build_stamps_ros2.sh):
     PBBI_LIB=build/stamps/libpbbi_stamps_ros2.so python tools/ros2_timeline.py [--exact]
-Stamps are s_memrealtime ticks (10 ns).  Read the timeline, never the run time of this build."""
+Stamps are s_memrealtime ticks (10 ns).  Read the timeline, never the run time of this build.
+Run with PBBI_FUSE_ITERS=1 for the timeline of ONE iteration per launch (what DESIGN.md 4.2 analyses);
+with fused launches stamps 2-4 are those of a wave's last iteration."""
 import ctypes as C
 import os
 import sys
