@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
 
 // ------------------------------------------------------------------------------------------------
 // k_sep_exact_hmc: the same parts-in-waves layout in the REFERENCE'S OPERATION ORDER (Leapfrog,
-// src/integrator.py:105-120, exactly as kernels_lane.hip::integrate_chain) -- the default of the drop-in
+// src/integrator.py:105-120, and Stormer-Verlet, :142-163, exactly as kernels_lane.hip::integrate_chain) -- the default of the drop-in
 // (PBBI_KDK_FMA not set).  State per lane q, v, a (96 VGPRs per 16 dims, four waves per SIMD); the
 // gradient of a separable potential is elementwise, so the trajectory needs nothing from the other
 // parts.  What ties the parts together is the ORDER of the two energy sums (p.p and the potential's
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
 // decision have the oracle's bits, like q and p.  Before: one chain per lane up to D = 64 (0.44 / 0.24
 // of the HBM roofline at D = 32 / 64) and the workspace kernels beyond (0.04).
 // ------------------------------------------------------------------------------------------------
-template <bool UNIT, bool FULL>
+template <bool UNIT, bool FULL, int METHOD>
 __global__ void __launch_bounds__(64 * MAXG) k_sep_exact_hmc(SepPrm prm) {
     __shared__ double run_pp[64], run_u[64];
     const int c = threadIdx.x & 63;
@@ -298,22 +298,44 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_exact_hmc(SepPrm prm) {
     const double oldH = hamiltonian();
 
     // ---- Leapfrog.integrate, src/integrator.py:105-120 (operation order of integrate_chain)
-    const double h = prm.h, hh2 = 0.5 * (prm.h * prm.h), hh = 0.5 * prm.h;
-#pragma unroll
-    for (int j = 0; j < DL; ++j) {
-        if constexpr (!UNIT) v[j] = v[j] / m;
+    const double h = prm.h, h2 = prm.h * prm.h, hh2 = 0.5 * h2, hh = 0.5 * prm.h;
+    auto accel = [&](int j) {  // -gradient / mass (src/integrator.py:73)
         const double g = pr[j] * (q[j] - mu[j]);
-        a[j] = UNIT ? -g : -g / m;
+        return UNIT ? -g : -g / m;
+    };
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    for (int s = 0; s < prm.L; ++s) {
+    if constexpr (METHOD == PBBI_LEAPFROG) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) a[j] = accel(j);
+        for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                q[j] += (v[j] * h + a[j] * hh2);
+                const double an = accel(j);
+                v[j] += (a[j] + an) * hh;
+                a[j] = an;
+            }
+        }
+    } else {  // Stormer-Verlet, src/integrator.py:142-163 (a[] becomes qPast after the first step)
 #pragma unroll
         for (int j = 0; j < DL; ++j) {
-            q[j] += (v[j] * h + a[j] * hh2);
-            const double g = pr[j] * (q[j] - mu[j]);
-            const double an = UNIT ? -g : -g / m;
-            v[j] += (a[j] + an) * hh;
-            a[j] = an;
+            const double q0 = q[j];
+            q[j] = (q0 + v[j] * h) + (0.5 * accel(j)) * h2;  // accel at q0: evaluated before q[j] changes
+            a[j] = q0;
         }
+        for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const double cur = q[j];
+                q[j] = (2.0 * cur - a[j]) + accel(j) * h2;
+                a[j] = cur;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = (q[j] - a[j]) / h;
     }
     if constexpr (!UNIT) {
 #pragma unroll
@@ -390,13 +412,13 @@ int sepn_hmc_iter(const IterArgs& a) {
     return PBBI_OK;
 }
 
-// the reference-order form of the same layout: harmonic / diagonal Gaussian, fp64, Leapfrog,
+// the reference-order form of the same layout: harmonic / diagonal Gaussian, fp64, both integrators,
 // 16 < D <= 256, PBBI_KDK_FMA not set
 bool sepx_applies(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     static const bool off = (getenv("PBBI_NO_SEPX") != nullptr);  // A/B switch
     return !off && (pot->kind == KIND_HARMONIC || pot->kind == KIND_GAUSS_DIAG) && pot->dtype == PBBI_F64 &&
-           a.method == PBBI_LEAPFROG && (a.flags & PBBI_KDK_FMA) == 0 && pot->D > 16 && pot->D <= DL * MAXG &&
+           (a.flags & PBBI_KDK_FMA) == 0 && pot->D > 16 && pot->D <= DL * MAXG &&
            (int64_t)DL * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
 }
 
@@ -411,13 +433,19 @@ int sepx_hmc_iter(const IterArgs& a) {
     const int G = (pot->D + DL - 1) / DL;
     const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
     const bool full = (pot->D % DL == 0);
-    if (a.mass) {
-        if (full) hipLaunchKernelGGL((k_sep_exact_hmc<false, true>), grid, block, 0, a.stream, prm);
-        else hipLaunchKernelGGL((k_sep_exact_hmc<false, false>), grid, block, 0, a.stream, prm);
-    } else {
-        if (full) hipLaunchKernelGGL((k_sep_exact_hmc<true, true>), grid, block, 0, a.stream, prm);
-        else hipLaunchKernelGGL((k_sep_exact_hmc<true, false>), grid, block, 0, a.stream, prm);
+#define SEPX_LAUNCH(U_, F_)                                                                                  \
+    {                                                                                                        \
+        if (a.method == PBBI_LEAPFROG)                                                                       \
+            hipLaunchKernelGGL((k_sep_exact_hmc<U_, F_, PBBI_LEAPFROG>), grid, block, 0, a.stream, prm);     \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_sep_exact_hmc<U_, F_, PBBI_STORMER_VERLET>), grid, block, 0, a.stream, prm); \
     }
+    if (a.mass) {
+        if (full) SEPX_LAUNCH(false, true) else SEPX_LAUNCH(false, false)
+    } else {
+        if (full) SEPX_LAUNCH(true, true) else SEPX_LAUNCH(true, false)
+    }
+#undef SEPX_LAUNCH
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

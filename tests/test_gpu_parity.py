@@ -1836,7 +1836,8 @@ def test_per_chain_steps_sampling_and_uturn_adaptation(P):
                                                   ("diag", 100, 257, True, True), ("harmonic", 128, 64, False, False),
                                                   ("diag", 250, 70, True, True), ("diag", 256, 129, False, True)])
 @pytest.mark.parametrize("rng", ["upload", "philox"])
-def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, compat, rng):
+@pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
+def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, compat, rng, method):
     """k_sep_exact_hmc (kernels_sepn.hip): 16-dim parts of a chain in the waves of a workgroup, the
     reference's operation order, energy sums continued from part to part -> q, p, ratio's decision
     BIT-EXACT with the oracle for harmonic / diagonal Gaussian potentials up to D = 256, the path the
@@ -1862,9 +1863,9 @@ def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, 
             p = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
             u = rs.uniform(size=N)
             u[::4] = 1.5
-            qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, m, h, L, compat=compat)
+            qo, po, ratio, rej = gpu_hmc_iter(lib, pot, method, q, p, u, m, h, L, compat=compat)
             q_or, p_or = q.copy(), p.copy()
-            r_or, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L, compat=flags)
+            r_or, rej_or = orc.hmc_iter(op, method, q_or, p_or, u, m, h, L, compat=flags)
             assert np.array_equal(rej, rej_or)
             assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
             fin = np.isfinite(r_or) & (r_or > 0)
@@ -1876,13 +1877,14 @@ def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, 
         qd = as_device(q, 0, np.float64)
         samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
         reject = empty((S, N), np.uint8, 0)
-        lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, samples.data_ptr(),
-                 momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, seed, 0, chain0, 1.0, st)
+        lib.call("pbbi_hmc_run", pot.handle, orc.METHODS[method], qd.data_ptr(), md.data_ptr() if mass else None,
+                 samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, seed, 0,
+                 chain0, 1.0, st)
         torch.cuda.synchronize()
         pstd = np.sqrt(m) if mass else None
         for i in range(S):
             p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, chain0, D, N, 1.0, pstd)
             u = device_uniform(lib, seed, i, chain0, N)
-            _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=flags)
+            _, rej = orc.hmc_iter(op, method, q, p, u, m, h, L, compat=flags)
             assert np.array_equal(to_numpy(reject[i]).astype(bool), rej)
             assert np.array_equal(to_numpy(samples[i]), q) and np.array_equal(to_numpy(momenta[i]), p)
