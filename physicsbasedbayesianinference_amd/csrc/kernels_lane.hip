@@ -682,6 +682,7 @@ int lane_hmc_iter(const IterArgs& a) {
     }
     if (sepn_applies(a)) return sepn_hmc_iter(a);
     if (sepx_applies(a)) return sepx_hmc_iter(a);  // separable, 16 < D <= 256, reference operation order
+    if (rosgx_applies(a)) return rosgx_hmc_iter(a);  // Rosenbrock, 32 < D <= 128, reference operation order
     if (rosg_applies(a)) return rosg_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 32 < D <= 128: 4 / 8 lanes of one wave
     if (rosn_applies(a)) return rosn_hmc_iter(a);  // PBBI_KDK_FMA, Rosenbrock, 128 < D <= 256: parts in waves  // PBBI_KDK_FMA, separable, 16 < D <= 256
     if (streams(a.pot)) return stream_hmc_iter(a);

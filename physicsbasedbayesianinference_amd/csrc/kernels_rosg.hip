@@ -35,6 +35,7 @@ struct RosgPrm {
     double h, a, b, inv_s, kT, c1, c2, c3;  // c1 = (-4b)/s, c2 = 2/s, c3 = (2b)/s
     int L, D, flags, rng;
     uint64_t seed, iter, chain0;
+    double cst;
 };
 
 template <int G>
@@ -198,6 +199,184 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_rosg_exact_hmc: the same G-lanes-per-chain layout in the REFERENCE'S OPERATION ORDER (Leapfrog,
+// src/integrator.py:105-120): kernels_lane2.hip's reference-order form generalised from 2 to G = 4 / 8
+// parts.  State per lane q, v, a of 16 dims; the gradient's nearest-neighbour terms cross the part
+// boundaries by shuffles (q of the next part's first dim comes down, the carried c3*t of the previous
+// part's last dim comes up); the energy sums run over the dimensions IN ORDER: the terms are formed
+// once, then G short passes pass the running sums from part to part (part k's lanes are final after
+// pass k).  q, p, the ratio's decision: bit-exact with the oracle.  Serves the drop-in's default
+// (PBBI_KDK_FMA not set) for 32 < D <= 128, where the workspace kernel ran at 0.10 / 0.04 of the HBM
+// roofline (D = 64 / 128).
+// ------------------------------------------------------------------------------------------------
+template <int G, bool UNIT, bool FULL>
+__global__ void __launch_bounds__(64, 2) k_rosg_exact_hmc(RosgPrm prm) {
+    constexpr int CPW = 64 / G;  // chains per wave
+    const int lane = threadIdx.x;
+    const int part = lane / CPW, c = lane % CPW;
+    const int64_t n0 = (int64_t)blockIdx.x * CPW;  // block-uniform
+    const int64_t left = prm.N - n0;
+    const bool valid = c < left;
+    const int cc = valid ? c : (int)left - 1;
+    const int D = prm.D;
+    const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
+    const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+    const uint32_t rin = 8u * (uint32_t)prm.ldn_in, rout = 8u * (uint32_t)prm.ldn_out;
+    const uint32_t vin = 8u * (uint32_t)cc + (uint32_t)(DL * part) * rin;
+    const uint32_t vout = 8u * (uint32_t)cc + (uint32_t)(DL * part) * rout;
+    const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0, D, prm.ldn_in, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0, D, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
+    auto exists = [&](int j) { return FULL ? true : DL * part + j < D; };
+    auto has_next = [&](int j) {  // dim 16*part + j has a right neighbour
+        if constexpr (FULL) return j + 1 < DL ? true : part + 1 < G;
+        return DL * part + j + 1 < D;
+    };
+    auto from_next = [&](double x) { return __shfl_down(x, CPW, 64); };
+    auto from_prev = [&](double x) { return __shfl_up(x, CPW, 64); };
+
+    double q[DL], v[DL], a[DL];  // v holds p, then the velocity, then p again
+#pragma unroll
+    for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
+    const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    auto draw = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float z[4];
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+        }
+    };
+    auto load_p = [&]() {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = buf_load<double>(bp, vin, (uint32_t)j * rin);
+    };
+    if (prm.rng) draw(); else load_p();
+
+    // H = 0.5 p.p / m + ((sum b t^2 + sum (a - q)^2) / s + cst), every sum in dimension order
+    auto hamiltonian = [&]() {
+        const double q_ext = from_next(q[0]);
+        double t[DL], bt[DL], r[DL], p2[DL];
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            t[j] = fma(-q[j], q[j], qn);
+            bt[j] = prm.b * t[j];
+            r[j] = prm.a - q[j];
+            p2[j] = v[j] * v[j];
+        }
+        double s1 = 0.0, s2 = 0.0, pp = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {  // pass k: part k continues part k-1's sums and becomes final
+            double r1 = k ? from_prev(s1) : 0.0, r2 = k ? from_prev(s2) : 0.0, r3 = k ? from_prev(pp) : 0.0;
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const double n1 = fma(bt[j], t[j], r1);
+                r1 = has_next(j) ? n1 : r1;
+            }
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                const double n2 = fma(r[j], r[j], r2);
+                r2 = has_next(j) ? n2 : r2;
+            }
+#pragma unroll
+            for (int j = 0; j < DL; ++j) r3 += p2[j];
+            if (k == 0 || part >= k) { s1 = r1; s2 = r2; pp = r3; }
+        }
+        // the last part holds the totals: every lane of the chain takes them
+        const int src = (G - 1) * CPW + c;
+        s1 = __shfl(s1, src, 64); s2 = __shfl(s2, src, 64); pp = __shfl(pp, src, 64);
+        return 0.5 * pp / m + ((s1 + s2) * prm.inv_s + prm.cst);
+    };
+    // visit(j, -g_j) in the oracle's operation order (kernels_lane2.hip::neg_grad_each, G parts)
+    const double nc1 = -prm.c1, nc3 = -prm.c3;
+    auto neg_grad_each = [&](auto&& visit) {
+        const double q_ext = from_next(q[0]);
+        const double t15 = fma(-q[DL - 1], q[DL - 1], q_ext);
+        const double nsec15 = has_next(DL - 1) ? nc3 * t15 : 0.0;
+        const double carry_ext = from_prev(nsec15);
+        double carry = part > 0 ? carry_ext : 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            const double tj = fma(-q[j], q[j], qn);
+            const double nfirst = fma(nc1 * q[j], tj, prm.c2 * (prm.a - q[j]));
+            const bool hn = has_next(j);
+            const double ngj = hn ? carry + nfirst : carry;
+            carry = hn ? nc3 * tj : 0.0;
+            visit(j, exists(j) ? ngj : 0.0);
+        }
+    };
+
+    const double oldH = hamiltonian();
+    // ---- Leapfrog.integrate, src/integrator.py:105-120 (operation order of kernels_lane.hip::integrate_chain)
+    const double h = prm.h, hh2 = 0.5 * (prm.h * prm.h), hh = 0.5 * prm.h;
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
+    }
+    neg_grad_each([&](int j, double ng) { a[j] = UNIT ? ng : ng / m; });
+    for (int s = 0; s < prm.L; ++s) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] += (v[j] * h + a[j] * hh2);
+        neg_grad_each([&](int j, double ng) {
+            const double an = UNIT ? ng : ng / m;
+            v[j] += (a[j] + an) * hh;
+            a[j] = an;
+        });
+    }
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
+    }
+    const double newH = hamiltonian();
+    const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
+    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    if (reject) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+#pragma unroll
+                for (int j = 0; j < DL; ++j) v[j] = q[j];
+            } else if (prm.rng) {
+                draw();
+            } else {
+                load_p();
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < DL; ++j) buf_store(bqo, vout, (uint32_t)j * rout, q[j]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j) buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
+        }
+        if (part == 0) {
+            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+        }
+    }
+}
+
+template <int G>
+void launch_exact(const IterArgs& a, const RosgPrm& prm, bool full) {
+    constexpr int CPW = 64 / G;
+    const dim3 grid((unsigned)((a.N + CPW - 1) / CPW)), block(64);
+    if (a.mass) {
+        if (full) hipLaunchKernelGGL((k_rosg_exact_hmc<G, false, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_rosg_exact_hmc<G, false, false>), grid, block, 0, a.stream, prm);
+    } else {
+        if (full) hipLaunchKernelGGL((k_rosg_exact_hmc<G, true, true>), grid, block, 0, a.stream, prm);
+        else hipLaunchKernelGGL((k_rosg_exact_hmc<G, true, false>), grid, block, 0, a.stream, prm);
+    }
+}
+
 template <int G>
 void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
     constexpr int CPW = 64 / G;
@@ -238,10 +417,34 @@ int rosg_hmc_iter(const IterArgs& a) {
                 (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
                 a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, inv_s, a.kT,
                 (-4.0 * pot->b) * inv_s, 2.0 * inv_s, (2.0 * pot->b) * inv_s, a.L, pot->D, a.flags,
-                a.rng, a.seed, a.iter, a.chain0};
+                a.rng, a.seed, a.iter, a.chain0, pot->cst};
     if (pot->D <= 32) launch<2>(a, prm, pot->D == 32);
     else if (pot->D <= 64) launch<4>(a, prm, pot->D == 64);
     else launch<8>(a, prm, pot->D == 128);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// the reference-order form: Rosenbrock, fp64, Leapfrog, 32 < D <= 128, PBBI_KDK_FMA not set
+bool rosgx_applies(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    static const bool off = (getenv("PBBI_NO_ROSGX") != nullptr);  // A/B switch
+    return !off && pot->kind == KIND_ROSENBROCK && pot->dtype == PBBI_F64 && a.method == PBBI_LEAPFROG &&
+           (a.flags & PBBI_KDK_FMA) == 0 && pot->D > 32 && pot->D <= 128 &&
+           (int64_t)pot->D * (a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) < ((int64_t)1 << 28);
+}
+
+int rosgx_hmc_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (a.N == 0) return PBBI_OK;
+    const double inv_s = 1.0 / pot->s;
+    RosgPrm prm{(const double*)a.q_in, (const double*)a.p_in, (const double*)a.u_in,
+                (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
+                a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, inv_s, a.kT,
+                (-4.0 * pot->b) * inv_s, 2.0 * inv_s, (2.0 * pot->b) * inv_s, a.L, pot->D, a.flags,
+                a.rng, a.seed, a.iter, a.chain0, pot->cst};
+    if (pot->D <= 64) launch_exact<4>(a, prm, pot->D == 64);
+    else launch_exact<8>(a, prm, pot->D == 128);
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }

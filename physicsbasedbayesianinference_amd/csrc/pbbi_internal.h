@@ -196,6 +196,9 @@ int rosn_hmc_iter(const IterArgs& a);
 // Rosenbrock, 32 < D <= 64 (128), PBBI_KDK_FMA: 4 (8) lanes of one wave per chain, kernels_rosg.hip
 bool rosg_applies(const IterArgs& a);
 int rosg_hmc_iter(const IterArgs& a);
+// ... and in the reference's operation order (bit-exact), 32 < D <= 128, PBBI_KDK_FMA not set
+bool rosgx_applies(const IterArgs& a);
+int rosgx_hmc_iter(const IterArgs& a);
 // the same potentials for D > 64 and for fp32: chain state in a device workspace, kernels_stream.hip
 int stream_hmc_iter(const IterArgs& a);
 int stream_integrate(const IntegrateArgs& a);

@@ -1888,3 +1888,51 @@ def test_separable_multiwave_reference_order_bitexact(P, lib, kind, D, N, mass, 
             _, rej = orc.hmc_iter(op, method, q, p, u, m, h, L, compat=flags)
             assert np.array_equal(to_numpy(reject[i]).astype(bool), rej)
             assert np.array_equal(to_numpy(samples[i]), q) and np.array_equal(to_numpy(momenta[i]), p)
+
+
+@pytest.mark.parametrize("D,N,mass,compat", [(33, 130, False, True), (48, 500, True, False), (64, 333, False, True),
+                                             (100, 130, True, True), (128, 64, False, False), (128, 257, True, True)])
+@pytest.mark.parametrize("rng", ["upload", "philox"])
+def test_rosenbrock_multilane_reference_order_bitexact(P, lib, D, N, mass, compat, rng):
+    """k_rosg_exact_hmc (kernels_rosg.hip): 4 / 8 lanes of one wave per chain, the reference's operation
+    order, energy sums passed from part to part in dimension order -> bit-exact with the oracle for
+    Rosenbrock at 32 < D <= 128 (the drop-in's default path there); rejections present."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D * 7 + N)
+    pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    h, L, S, seed, chain0 = 0.05, 10, 3, 9, 4321
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    flags = lib.COMPAT_P_FROM_OLDQ if compat else 0
+    q = np.ascontiguousarray(1.0 + 0.3 * rs.standard_normal((D, N)))
+    n_rej = 0
+    if rng == "upload":
+        for it in range(S):
+            p = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+            u = rs.uniform(size=N)
+            u[::5] = 1.5
+            qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, m, h, L, compat=compat)
+            q_or, p_or = q.copy(), p.copy()
+            r_or, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, m, h, L, compat=flags)
+            assert np.array_equal(rej, rej_or)
+            assert np.array_equal(qo, q_or) and np.array_equal(po, p_or)
+            fin = np.isfinite(r_or) & (r_or > 0)
+            assert np.max(np.abs(np.log(ratio[fin]) - np.log(r_or[fin]))) < 1e-9
+            n_rej += int(rej.sum())
+            q = qo
+        assert n_rej >= S * (N // 5)
+    else:
+        md = as_device(m, 0, np.float64) if mass else None
+        qd = as_device(q, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject = empty((S, N), np.uint8, 0)
+        lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, samples.data_ptr(),
+                 momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, seed, 0, chain0, 1.0, stream_ptr(0))
+        torch.cuda.synchronize()
+        pstd = np.sqrt(m) if mass else None
+        for i in range(S):
+            p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, chain0, D, N, 1.0, pstd)
+            u = device_uniform(lib, seed, i, chain0, N)
+            _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=flags)
+            assert np.array_equal(to_numpy(reject[i]).astype(bool), rej)
+            assert np.array_equal(to_numpy(samples[i]), q) and np.array_equal(to_numpy(momenta[i]), p)
