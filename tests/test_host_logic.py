@@ -265,3 +265,48 @@ def test_oracle_custom_potential_matches_numpy():
     U, g = orc.potential(orc.pot_custom(LOGISTIC, X.shape[1], prm), q, want_grad=True)
     Un, gn = logistic_numpy(X, y, lam, q)
     assert np.allclose(U, Un, rtol=1e-12) and np.allclose(g, gn, rtol=1e-11, atol=1e-12)
+
+
+# ------------------------------------------------------------------ bench.py launcher logic (no GPU)
+def test_bench_self_launches_the_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (a child torchrun on
+    127.0.0.1, created before anything touches the GPU) and passes the child's exit code through; with
+    a launcher of another world size it refuses instead of printing single-GPU numbers for every N."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.main() == 7
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a launcher that started another number of ranks: error, not a silent single-GPU run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    assert bench.main() == 2
+    assert len(calls) == 1
+
+
+def test_warmup_key_and_flag_values_match_the_header():
+    """The Python constants mirror include/pbbi.h (flags, streams) and the warm-up key differs from any seed."""
+    from physicsbasedbayesianinference_amd import _lib
+    from physicsbasedbayesianinference_amd.HMC import WARMUP_SEED_MASK
+    hdr = open(os.path.join(ROOT, "include", "pbbi.h")).read()
+    for name, val in (("PBBI_COMPAT_P_FROM_OLDQ", _lib.COMPAT_P_FROM_OLDQ), ("PBBI_KDK_FMA", _lib.KDK_FMA),
+                      ("PBBI_BETA_ACCEPT", _lib.BETA_ACCEPT), ("PBBI_PER_CHAIN_STEPS", _lib.PER_CHAIN_STEPS),
+                      ("PBBI_UTURN_STOP", _lib.UTURN_STOP), ("PBBI_STREAM_STEPS", _lib.STREAM_STEPS)):
+        assert re.search(r"\b%s\s*=\s*%d\b" % (name, val), hdr), name
+    assert WARMUP_SEED_MASK != 0 and (5 ^ WARMUP_SEED_MASK) != 5
