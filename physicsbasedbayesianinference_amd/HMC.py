@@ -31,7 +31,7 @@ HBM-bound.  kdk_fma=False keeps the reference's operation 
 import numpy as np
 from scipy.constants import Boltzmann as boltzmannConst
 
-from . import _lib
+from . import _hoststream, _lib
 from ._device import as_device, empty, stream_ptr, synchronize, to_numpy
 from .integrator import Leapfrog, StormerVerlet, mass_or_none, resolve_potential
 
@@ -56,6 +56,7 @@ class _HostDrawPipeline:
         self.t, self.S, self.draw = t, int(S), draw
         self.draw_seconds = 0.0
         self.ready = queue.Queue()
+        self.direct = np.dtype(np_dtype) == np.dtype(np.float64)
         self.error = None
         self.thread = None
         self.stop = False
@@ -86,9 +87,6 @@ class _HostDrawPipeline:
             for i in range(self.S):
                 if self.stop:  # the consumer gave up (an error in a launch): leave the rest of the stream undrawn
                     return
-                t0 = time.perf_counter()
-                p, u = self.draw(i)
-                self.draw_seconds += time.perf_counter() - t0
                 # a slot is reused only after the consumer has LAUNCHED the kernel that reads it (it comes
                 # back through `free`) and that kernel has finished (its event)
                 s = self.free.get()
@@ -96,8 +94,15 @@ class _HostDrawPipeline:
                     return
                 if s.consumed is not None:
                     s.consumed.synchronize()
-                s.pin_p.copy_(t.from_numpy(np.ascontiguousarray(p)))   # also converts float64 -> the handle's dtype
-                s.pin_u.copy_(t.from_numpy(np.ascontiguousarray(u)))
+                t0 = time.perf_counter()
+                if self.direct:   # float64 handle: the draws are written into the pinned buffers themselves
+                    self.draw(i, s.pin_p.numpy(), s.pin_u.numpy())
+                    self.draw_seconds += time.perf_counter() - t0
+                else:
+                    p, u = self.draw(i)
+                    self.draw_seconds += time.perf_counter() - t0
+                    s.pin_p.copy_(t.from_numpy(np.ascontiguousarray(p)))   # converts float64 -> the handle's dtype
+                    s.pin_u.copy_(t.from_numpy(np.ascontiguousarray(u)))
                 with t.cuda.stream(self.side):
                     s.p.copy_(s.pin_p, non_blocking=True)
                     s.u.copy_(s.pin_u, non_blocking=True)
@@ -306,15 +311,23 @@ class HMC:
             q_prev = as_device(self.integrator.q, dev, dt)
             kT_host = float(boltzmannConst * temperature) if self.beta_accept else 1.0
 
-            def draw(i):
+            def draw(i, pin_p=None, pin_u=None):
+                """Iteration i's draws in the reference's order (p, then u).  With float64 upload buffers
+                (pin_p, pin_u: NumPy views of pinned memory) they are written there directly."""
                 if self.verbose and i % 100 == 0:
                     print("HMC iteration ", i + 1)                           # :151-152
-                if host_stream is None:
+                if host_stream is None and pin_p is not None:
+                    pStd = np.sqrt(ens.mass * boltzmannConst * temperature)  # src/ensemble.py:88
+                    p = ens.p = _hoststream.scaled_normal_into(pin_p, pStd)  # :89-91, :154
+                    u = _hoststream.uniform_into(pin_u)                      # :168
+                elif host_stream is None:
                     p = ens.setMomentum(temperature)                         # :154
-                    u = np.random.uniform(size=N)                            # :168
+                    u = _hoststream.uniform(N)                               # :168 (np.random.uniform(size=N))
                 else:
                     p = ens.p = host_stream.momenta(ens.mass, temperature)
                     u = host_stream.uniforms()
+                    if pin_p is not None:
+                        pin_p[...], pin_u[...] = p, u
                 self.integrator.p = p
                 return p, u
             # The NumPy legacy stream can only be drawn in order, on the host (~15 ns per normal):
@@ -383,6 +396,7 @@ class HMC:
             # leave the ensemble where the reference leaves it: q, p alias the final state
             if rng != "numpy":
                 self.integrator.q = ens.q = np.empty((D, N))
+            if rng != "numpy" or pipe.direct:   # (the last draw lives in a pinned upload buffer)
                 self.integrator.p = ens.p = np.empty((D, N))
             self.integrator.q[...] = to_numpy(samples[S - 1])
             self.integrator.p[...] = to_numpy(momenta[S - 1])

@@ -17,6 +17,8 @@ Reproducibility across shardings:
 import numpy as np
 from scipy.constants import k as boltzmannConst
 
+from . import _hoststream
+
 __all__ = ["ensemble_weights", "shard_bounds", "HostStream", "gather_samples", "get_samples_sharded"]
 
 
@@ -45,14 +47,14 @@ class HostStream:
 
     def positions(self, qStd):
         return np.ascontiguousarray(
-            (np.random.standard_normal((self.D, self.N)) * qStd)[:, self.lo:self.hi])
+            (_hoststream.standard_normal((self.D, self.N)) * qStd)[:, self.lo:self.hi])
 
     def momenta(self, mass_local, temperature):
-        z = np.random.standard_normal((self.D, self.N))[:, self.lo:self.hi]
+        z = _hoststream.standard_normal((self.D, self.N))[:, self.lo:self.hi]
         return np.ascontiguousarray(z * np.sqrt(np.asarray(mass_local) * boltzmannConst * temperature))
 
     def uniforms(self):
-        return np.ascontiguousarray(np.random.uniform(size=self.N)[self.lo:self.hi])
+        return np.ascontiguousarray(_hoststream.uniform(self.N)[self.lo:self.hi])
 
 
 def _dist():

@@ -12,9 +12,13 @@ RandomState exactly as the reference's `scipy.stats.norm.rvs(scale, size)` does:
 (verified bit-exact against the reference in tests/golden).  This
 host stream is what "identical seeds" means for the reference; the device-side
 Philox stream (`HMC.getSamples(..., rng="philox")`) is the throughput mode.
+Large draws go through `_hoststream` (csrc/hoststream.c): the same global stream and the same
+state afterwards, bit for bit, with the Box-Muller transform spread over the host's cores.
 """
 import numpy as np
 from scipy.constants import k as boltzmannConst
+
+from . import _hoststream
 
 __all__ = ["Ensemble", "boltzmannConst"]
 
@@ -31,13 +35,13 @@ class Ensemble:
 
     def setPosition(self, qStd):
         """src/ensemble.py:63-76.  Rebinds and returns self.q (a NEW array)."""
-        self.q = np.random.standard_normal((self.numDimensions, self.numParticles)) * qStd
+        self.q = _hoststream.standard_normal((self.numDimensions, self.numParticles)) * qStd
         return self.q
 
     def setMomentum(self, temperature):
         """src/ensemble.py:78-93: p ~ N(0, mass*kB*T) per particle.  Rebinds self.p."""
         pStd = np.sqrt(self.mass * boltzmannConst * temperature)
-        self.p = np.random.standard_normal((self.numDimensions, self.numParticles)) * pStd
+        self.p = _hoststream.standard_normal((self.numDimensions, self.numParticles)) * pStd
         return self.p
 
     def particle(self, particleNum):

@@ -310,3 +310,82 @@ def test_warmup_key_and_flag_values_match_the_header():
                       ("PBBI_UTURN_STOP", _lib.UTURN_STOP), ("PBBI_STREAM_STEPS", _lib.STREAM_STEPS)):
         assert re.search(r"\b%s\s*=\s*%d\b" % (name, val), hdr), name
     assert WARMUP_SEED_MASK != 0 and (5 ^ WARMUP_SEED_MASK) != 5
+
+
+# ------------------------------------------------------------------ the fast host stream (csrc/hoststream.c)
+def test_fast_host_stream_is_numpys_legacy_stream_bit_for_bit(monkeypatch):
+    """_hoststream.standard_normal / uniform return exactly np.random's legacy draws from the same
+    global state and leave exactly NumPy's state behind (key, position, cached gaussian): odd and even
+    counts, a cached variate at entry, block boundaries of MT19937, interleaving with np.random calls."""
+    from physicsbasedbayesianinference_amd import _hoststream as hs
+    assert hs.available(), "libpbbi_host.so missing: python -m physicsbasedbayesianinference_amd.build"
+    monkeypatch.setattr(hs, "MIN_FAST", 1)
+
+    def same_state(a, b):
+        return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    for seed in (0, 1234, 2 ** 32 - 1):
+        for sizes in ([1, 2, 3, 5, 8], [1000, 1001, 77], [624 * 3, 313, 1, 1, 99999], [(7, 4001)], [262144 + 1]):
+            np.random.seed(seed)
+            ref = []
+            for i, n in enumerate(sizes):
+                ref += [np.random.standard_normal(n), np.random.uniform(size=int(np.prod(n)) // 3 + i + 1)]
+            st_ref = np.random.get_state()
+            np.random.seed(seed)
+            got = []
+            for i, n in enumerate(sizes):
+                got += [hs.standard_normal(n), hs.uniform(int(np.prod(n)) // 3 + i + 1)]
+            assert all(np.array_equal(a, b) and a.shape == b.shape for a, b in zip(ref, got)), (seed, sizes)
+            assert same_state(st_ref, np.random.get_state()), (seed, sizes)
+    # a NumPy draw that leaves a cached gaussian, then the fast path, then NumPy again
+    np.random.seed(3)
+    ref = [np.random.standard_normal(3), np.random.standard_normal(100001), np.random.uniform(size=7),
+           np.random.standard_normal(2)]
+    np.random.seed(3)
+    got = [np.random.standard_normal(3), hs.standard_normal(100001), np.random.uniform(size=7),
+           np.random.standard_normal(2)]
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+
+
+def test_fast_host_stream_in_place_draws(monkeypatch):
+    """scaled_normal_into / uniform_into (the class API's per-iteration draws, written straight into the
+    upload buffers) equal `standard_normal((D, N)) * pStd` and `uniform(size=N)` bit for bit, state included;
+    wrong buffers are refused."""
+    from physicsbasedbayesianinference_amd import _hoststream as hs
+    for min_fast in (1, 1 << 40):            # the C path and the NumPy path of the same functions
+        monkeypatch.setattr(hs, "MIN_FAST", min_fast)
+        for D, N in ((3, 7), (128, 1001), (5, 1), (1, 40000)):
+            scale = np.random.RandomState(D).uniform(0.5, 2.0, N)
+            np.random.seed(11)
+            np.random.standard_normal(1)       # leaves a cached variate
+            ref_p, ref_u = np.random.standard_normal((D, N)) * scale, np.random.uniform(size=N)
+            ref_state = np.random.get_state()
+            np.random.seed(11)
+            np.random.standard_normal(1)
+            p, u = np.full((D, N), np.nan), np.full(N, np.nan)
+            assert hs.scaled_normal_into(p, scale) is p and hs.uniform_into(u) is u
+            got_state = np.random.get_state()
+            assert np.array_equal(p, ref_p) and np.array_equal(u, ref_u), (D, N, min_fast)
+            assert np.array_equal(ref_state[1], got_state[1]) and ref_state[2:] == got_state[2:]
+    with pytest.raises(ValueError):
+        hs.scaled_normal_into(np.zeros((4, 6), np.float32), np.ones(6))
+    with pytest.raises(ValueError):
+        hs.scaled_normal_into(np.zeros((4, 6)), np.ones(4))
+    with pytest.raises(ValueError):
+        hs.uniform_into(np.zeros((4, 6))[:, ::2])
+
+
+def test_ensemble_draws_through_the_fast_stream_match_the_golden_run(monkeypatch):
+    """Ensemble.setPosition / setMomentum on the fast stream reproduce the reference's recorded draws."""
+    import physicsbasedbayesianinference_amd as P
+    from physicsbasedbayesianinference_amd import _hoststream as hs
+    from conftest import load_golden
+    from scipy.constants import k as kB
+    monkeypatch.setattr(hs, "MIN_FAST", 1)
+    g = load_golden("G4_getsamples_dense_d128")
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(int(g["D"]), int(g["N"]))
+    ens.mass = g["mass"].copy()
+    assert np.array_equal(ens.setPosition(float(g["qStd"])), g["q0"])
+    for i in range(int(g["S"])):
+        assert np.array_equal(ens.setMomentum(float(g["temperature"])), g["p_draw"][i])
+        assert np.array_equal(hs.uniform(int(g["N"])), g["u"][i])
