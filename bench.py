@@ -333,8 +333,8 @@ def bench_parity(args):
                    "accept_rate": hmc.acceptRate,
                    "host_rng_ms_per_step": getattr(hmc, "host_rng_ms", None),
                    "note": "wall time of the whole getSamples call: NumPy legacy-stream draws on the host "
-                           "+ H2D + kernels; value is bounded by the host's single-thread polar "
-                           "Box-Muller rate"}}
+                           "(libpbbi_host.so: the same stream bit for bit, transform spread over the "
+                           "cores) + H2D + kernels; bounded by the host generator, not the GPU"}}
 
 
 def bench_c2(args, rank, world, local_rank):

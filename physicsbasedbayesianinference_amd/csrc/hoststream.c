@@ -9,9 +9,10 @@
  * rejection loop, the same libm log / sqrt NumPy's own C code calls -- but splits the work:
  *   1. MT19937 raw words, sequential by nature, block by block (three dependence-free phases per
  *      624-word block, which the compiler vectorises);
- *   2. the polar transform of the attempts (4 words each), IN PARALLEL over chunks of the word buffer
- *      (OpenMP): accept flags -> per-chunk counts -> exclusive prefix -> every chunk writes its
- *      accepted pairs at their final positions (f*x2 first, then f*x1: legacy_gauss returns the
+ *   2. the polar transform of the attempts (4 words each), IN PARALLEL over chunks of the block buffer
+ *      and overlapped with 1.: one thread generates, the others take chunks in order, count each chunk's
+ *      accepted attempts, chain the running count from the chunk before (a single-pass scan) and write
+ *      the accepted pairs at their final positions (f*x2 first, then f*x1: legacy_gauss returns the
  *      second variate first and caches the first).
  * The state that goes back to NumPy (key, pos, has_gauss, cached gaussian) is exactly what its own
  * generator would have left, so draws before and after interleave freely with np.random calls.
@@ -21,7 +22,12 @@
  * Mirrors numpy/random/src/legacy/legacy-distributions.c (legacy_gauss, legacy_double) and
  * numpy/random/src/mt19937/mt19937.c (mt19937_gen, tempering) -- algorithms restated, no code copied.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <math.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -46,7 +52,7 @@ typedef struct {
 
 /* next block of 624 untempered state words from the previous one (the MT19937 recurrence) */
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
-__attribute__((target_clones("avx2", "default")))
+__attribute__((target_clones("avx512f", "avx2", "default")))
 #endif
 static void mt_next_block(const uint32_t* restrict old, uint32_t* restrict nw) {
     int i;
@@ -92,6 +98,8 @@ static uint32_t* g_blocks = NULL;
 static size_t g_cap_blocks = 0;
 static uint32_t* g_words = NULL;
 static size_t g_cap_words = 0;
+static char* g_scratch = NULL;
+static size_t g_cap_scratch = 0;
 static volatile int g_busy = 0;
 
 static int stream_init(hs_stream* s, const hs_state* st) {
@@ -168,10 +176,10 @@ static inline double words_to_double(uint32_t a, uint32_t b) {  /* mt19937 rando
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-/* one polar attempt from 4 words: returns 1 and (first, second) = (f*x2, f*x1) when accepted */
+/* one polar attempt from 4 UNTEMPERED words: returns 1 and (first, second) = (f*x2, f*x1) when accepted */
 static inline int attempt(const uint32_t* w, double* first, double* second) {
-    const double x1 = 2.0 * words_to_double(w[0], w[1]) - 1.0;
-    const double x2 = 2.0 * words_to_double(w[2], w[3]) - 1.0;
+    const double x1 = 2.0 * words_to_double(temper(w[0]), temper(w[1])) - 1.0;
+    const double x2 = 2.0 * words_to_double(temper(w[2]), temper(w[3])) - 1.0;
     const double r2 = x1 * x1 + x2 * x2;
     if (r2 >= 1.0 || r2 == 0.0) return 0;
     {
@@ -182,15 +190,20 @@ static inline int attempt(const uint32_t* w, double* first, double* second) {
     }
 }
 
-static inline int attempt_accepts(const uint32_t* w) {
-    const double x1 = 2.0 * words_to_double(w[0], w[1]) - 1.0;
-    const double x2 = 2.0 * words_to_double(w[2], w[3]) - 1.0;
-    const double r2 = x1 * x1 + x2 * x2;
-    return !(r2 >= 1.0 || r2 == 0.0);
+/* waiting for another thread's result: a few pause instructions, then give the CPU away (more threads
+ * than free cores must not starve the thread everybody waits for) */
+static inline void spin_pause(unsigned* spins) {
+    if (++*spins < 64) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    } else {
+        sched_yield();
+    }
 }
 
 /* out[0 .. n) = the next n legacy standard normals of the state; the state is advanced.
- * Returns 0, or -1 when memory runs out (state untouched). */
+ * Returns 0, or -1 when memory runs out / the stream is in use (state untouched). */
 static int normal_core(hs_state* st, double* out, int64_t n, const double* scale, int64_t ncol);
 
 int pbbi_host_standard_normal(hs_state* st, double* out, int64_t n) {
@@ -205,98 +218,290 @@ int pbbi_host_scaled_normal(hs_state* st, double* out, int64_t n, const double* 
     return normal_core(st, out, n, scale, ncol);
 }
 
+/* One pass over `nch` chunks of CH attempts starting at attempt `att0` of the stream (word pos0 + 4*att0
+ * of the block buffer), pipelined: thread 0 runs the MT19937 recurrence (the only sequential part) and
+ * publishes how many blocks are complete; the other threads take chunks in order, count each chunk's
+ * accepted attempts, chain the running count from the chunk before (published per chunk, as in a
+ * single-pass scan) and write their pairs at the final positions.  Thread 0 joins them when the blocks are
+ * done.  No barrier inside; every wait is on something an earlier ticket or thread 0 produces. */
+typedef struct {
+    hs_stream* s;
+    double* out;
+    const double* scale;
+    int64_t ncol, n, done, pairs, acc0, att0, nch, CH;
+    size_t blocks_target;          /* n_blocks to reach */
+    volatile int64_t* pref;        /* inclusive running count after chunk c; -1 = not yet */
+    char* scratch;                 /* per thread: the pairs of the chunk in flight + their attempt indices */
+    double last_second;            /* the variate an odd request leaves cached */
+    /* the three words the threads talk through, one cache line each: the generator's progress is polled by
+     * every waiting worker, and a store to a line 15 cores spin on costs a coherence round per store */
+    char pad0[128];
+    volatile size_t blocks_ready;
+    char pad1[128 - sizeof(size_t)];
+    volatile int64_t next_chunk;
+    char pad2[128 - sizeof(int64_t)];
+    volatile int64_t end_attempt;  /* attempt (within the pass) that supplies the last pair; -1 = none */
+    char pad3[128 - sizeof(int64_t)];
+} hs_pass;
+
+#define HS_SCRATCH_PER_THREAD(CH) ((size_t)(CH) * (2 * sizeof(double) + sizeof(int32_t)))
+#define HS_PUBLISH_EVERY 32   /* blocks per progress store (a chunk is 210 blocks) */
+
+#ifdef HS_PROFILE   /* tools/ubench/hoststream_phases.c: where a pass spends its time, per thread */
+#include <stdio.h>
+#include <time.h>
+static double hs_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static double hs_prof[256][6];  /* generate, wait blocks, count, wait prefix, write, chunks */
+#define HS_T(var) const double var = hs_now()
+#define HS_ADD(slot, a, b) hs_prof[omp_get_thread_num() & 255][slot] += (b) - (a)
+#else
+#define HS_T(var)
+#define HS_ADD(slot, a, b)
+#endif
+
+static void pass_generate(hs_pass* ps) {
+    hs_stream* s = ps->s;
+    HS_T(t0);
+    while (s->n_blocks < ps->blocks_target) {
+        if (__atomic_load_n(&ps->end_attempt, __ATOMIC_RELAXED) >= 0) break;  /* the request is complete */
+        for (int b = 0; b < HS_PUBLISH_EVERY && s->n_blocks < ps->blocks_target; ++b) {
+            mt_next_block(s->blocks + (s->n_blocks - 1) * MT_N, s->blocks + s->n_blocks * MT_N);
+            ++s->n_blocks;
+        }
+        __atomic_store_n(&ps->blocks_ready, s->n_blocks, __ATOMIC_RELEASE);
+    }
+    /* whoever still waits for blocks past an early stop is released by end_attempt (checked in the wait) */
+    HS_T(t1);
+    HS_ADD(0, t0, t1);
+}
+
+static void pass_work(hs_pass* ps, int tid) {
+    const hs_stream* s = ps->s;
+    const int64_t CH = ps->CH, pairs = ps->pairs, n = ps->n, done = ps->done, ncol = ps->ncol;
+    const double* scale = ps->scale;
+    double* out = ps->out;
+    double* tmp = (double*)(ps->scratch + (size_t)tid * HS_SCRATCH_PER_THREAD(CH));
+    int32_t* att_of = (int32_t*)(tmp + CH * 2);   /* attempt index of the chunk's k-th pair */
+    for (;;) {
+        const int64_t c = __atomic_fetch_add(&ps->next_chunk, 1, __ATOMIC_RELAXED);
+        if (c >= ps->nch) return;
+        if (__atomic_load_n(&ps->end_attempt, __ATOMIC_ACQUIRE) >= 0) {  /* past the end of the request */
+            __atomic_store_n(&ps->pref[c], pairs, __ATOMIC_RELEASE);
+            continue;
+        }
+        const size_t w0 = (size_t)s->pos0 + (size_t)(ps->att0 + c * CH) * 4;
+        const size_t need_blocks = (w0 + (size_t)CH * 4 + MT_N - 1) / MT_N;
+        int skip = 0;
+        unsigned spins = 0;
+        HS_T(t0);
+        while (__atomic_load_n(&ps->blocks_ready, __ATOMIC_ACQUIRE) < need_blocks) {
+            if (__atomic_load_n(&ps->end_attempt, __ATOMIC_ACQUIRE) >= 0) { skip = 1; break; }
+            spin_pause(&spins);
+        }
+        if (skip) {
+            __atomic_store_n(&ps->pref[c], pairs, __ATOMIC_RELEASE);
+            continue;
+        }
+        const uint32_t* wc = s->blocks + w0;
+        int64_t kc = 0;
+        HS_T(t1);
+        for (int64_t a = 0; a < CH; ++a) {  /* transform once, into the thread's own (L2-resident) buffer */
+            double f, g;
+            if (attempt(wc + a * 4, &f, &g)) {
+                tmp[2 * kc] = f;
+                tmp[2 * kc + 1] = g;
+                att_of[kc] = (int32_t)a;
+                ++kc;
+            }
+        }
+        HS_T(t2);
+        int64_t k = ps->acc0;
+        if (c > 0) {
+            spins = 0;
+            while ((k = __atomic_load_n(&ps->pref[c - 1], __ATOMIC_ACQUIRE)) < 0) spin_pause(&spins);
+        }
+        __atomic_store_n(&ps->pref[c], k + kc, __ATOMIC_RELEASE);
+        HS_T(t3);
+        HS_ADD(1, t0, t1); HS_ADD(2, t1, t2); HS_ADD(3, t2, t3);
+        if (k >= pairs) continue;
+        {   /* the chunk's pairs go to out[done + 2k ...]; the request may end inside the chunk */
+            const int64_t take = (pairs - k < kc) ? pairs - k : kc;
+            const int64_t o0 = done + 2 * k;
+            int64_t cnt = 2 * take;
+            if (o0 + cnt > n) {  /* only the very last pair of an odd request: its second variate is cached */
+                cnt = n - o0;
+                ps->last_second = tmp[2 * take - 1];
+            }
+            if (scale) {
+                int64_t col = o0 % ncol;
+                for (int64_t i = 0; i < cnt; ++i) {
+                    out[o0 + i] = tmp[i] * scale[col];
+                    if (++col == ncol) col = 0;
+                }
+            } else {
+                memcpy(out + o0, tmp, (size_t)cnt * sizeof(double));
+            }
+            if (k + take == pairs) __atomic_store_n(&ps->end_attempt, c * CH + att_of[take - 1], __ATOMIC_RELEASE);
+        }
+        HS_T(t4);
+        HS_ADD(4, t3, t4);
+#ifdef HS_PROFILE
+        hs_prof[omp_get_thread_num() & 255][5] += 1;
+#endif
+    }
+}
+
+/* The threads of a pass work on each other's cache lines (the generator's blocks, the running counts):
+ * on a two-socket host they are kept on the NUMA node the caller runs on for the length of the call
+ * (measured on the GPU box's 2 x EPYC 9575F, 16 threads: 4.5 ms per C2 draw on one node, 7-12 ms
+ * scattered over both).  Every thread's own affinity mask is put back when the pass ends.
+ * PBBI_HOST_NO_PIN=1 leaves placement to the scheduler. */
+#if defined(__linux__)
+#define HS_MAX_NODES 16
+static int g_nodes = -1;               /* -1 = /sys not read yet */
+static cpu_set_t g_node_cpus[HS_MAX_NODES];
+
+static void read_nodes(void) {
+    g_nodes = 0;
+    const char* off = getenv("PBBI_HOST_NO_PIN");
+    if (off && off[0] == '1') return;
+    for (int nd = 0; nd < HS_MAX_NODES; ++nd) {
+        char path[96], buf[4096];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", nd);
+        FILE* f = fopen(path, "r");
+        if (!f) break;
+        const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[got] = 0;
+        CPU_ZERO(&g_node_cpus[nd]);
+        const char* p = buf;
+        while (*p) {   /* "0-63,128-191" */
+            char* e;
+            long a = strtol(p, &e, 10), b;
+            if (e == p) break;
+            b = a;
+            if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &g_node_cpus[nd]);
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',') break;
+        }
+        g_nodes = nd + 1;
+    }
+    if (g_nodes < 2) g_nodes = 0;      /* one node: nothing to choose */
+}
+
+/* the CPUs of the caller's node that the caller is allowed on; 0 when there is no reason to pin */
+static int pass_cpus(cpu_set_t* target, int threads) {
+    if (g_nodes < 0) read_nodes();
+    if (g_nodes == 0) return 0;
+    const int cpu = sched_getcpu();
+    cpu_set_t allowed;
+    if (cpu < 0 || sched_getaffinity(0, sizeof(allowed), &allowed)) return 0;
+    for (int nd = 0; nd < g_nodes; ++nd) {
+        if (!CPU_ISSET(cpu, &g_node_cpus[nd])) continue;
+        CPU_AND(target, &g_node_cpus[nd], &allowed);
+        return CPU_COUNT(target) >= threads;   /* a node with fewer usable CPUs than threads: do not squeeze */
+    }
+    return 0;
+}
+#define HS_PIN_BEGIN(target, pinned) cpu_set_t hs_old; const int hs_pin = (pinned) && \
+    !sched_getaffinity(0, sizeof(hs_old), &hs_old) && !sched_setaffinity(0, sizeof(cpu_set_t), (target))
+#define HS_PIN_END() do { if (hs_pin) sched_setaffinity(0, sizeof(hs_old), &hs_old); } while (0)
+#else
+typedef int cpu_set_t;
+static int pass_cpus(cpu_set_t* target, int threads) { (void)target; (void)threads; return 0; }
+#define HS_PIN_BEGIN(target, pinned)
+#define HS_PIN_END()
+#endif
+
 static int normal_core(hs_state* st, double* out, int64_t n, const double* scale, int64_t ncol) {
     if (n <= 0) return 0;
     const int had_gauss = st->has_gauss;
     const double old_gauss = st->gauss;
     int64_t done = 0;
-#define SCALED(i, v) ((scale) ? (v) * scale[(i) % ncol] : (v))
+    hs_stream s;
+    if (stream_init(&s, st)) return -1;
     if (st->has_gauss) {  /* the cached variate goes first */
-        out[0] = SCALED(0, st->gauss);
+        out[0] = scale ? st->gauss * scale[0] : st->gauss;
         ++done;
         st->has_gauss = 0;
         st->gauss = 0.0;
-        if (done == n) return 0;
+        if (done == n) { stream_free(&s); return 0; }
     }
     const int64_t pairs = (n - done + 1) / 2;  /* accepted attempts needed (the last may leave a cached variate) */
-    hs_stream s;
-    if (stream_init(&s, st)) {
-        st->has_gauss = had_gauss;
-        st->gauss = old_gauss;
-        return -1;
-    }
-    const int64_t CH = 1 << 15;                /* attempts per chunk */
+    const int64_t CH = 1 << 15;                /* attempts per chunk: 512 KB of words, L2-resident between the two passes */
     int64_t att_done = 0, acc_done = 0;        /* attempts examined, pairs written */
-    int64_t* counts = NULL;
+    int64_t* pref = NULL;
+    double last_second = 0.0;
     int rc = 0;
+    const int threads = g_threads;
+    if (g_cap_scratch < (size_t)threads * HS_SCRATCH_PER_THREAD(CH)) {  /* (under g_busy, like the other buffers) */
+        char* ns = (char*)realloc(g_scratch, (size_t)threads * HS_SCRATCH_PER_THREAD(CH));
+        if (!ns) { st->has_gauss = had_gauss; st->gauss = old_gauss; stream_free(&s); return -1; }
+        g_scratch = ns;
+        g_cap_scratch = (size_t)threads * HS_SCRATCH_PER_THREAD(CH);
+    }
+    cpu_set_t node_cpus;
+    const int pin = threads > 1 && pass_cpus(&node_cpus, threads);
+    (void)pin;
     while (acc_done < pairs) {
         /* expected attempts for what is missing, plus a margin; at least one chunk */
         int64_t want = (int64_t)((double)(pairs - acc_done) / 0.7853981633974483 * 1.02) + 1024;
         const int64_t nch = (want + CH - 1) / CH;
         want = nch * CH;
-        if (stream_ensure(&s, (size_t)(att_done + want) * 4)) { rc = -1; break; }
-        int64_t* nc = (int64_t*)realloc(counts, (size_t)(nch + 1) * sizeof(int64_t));
-        if (!nc) { rc = -1; break; }
-        counts = nc;
-        const uint32_t* w = s.words + (size_t)att_done * 4;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
-        for (int64_t c = 0; c < nch; ++c) {
-            int64_t k = 0;
-            const uint32_t* wc = w + (size_t)c * CH * 4;
-            for (int64_t a = 0; a < CH; ++a) k += attempt_accepts(wc + a * 4);
-            counts[c] = k;
+        hs_pass ps;
+        memset(&ps, 0, sizeof(ps));
+        ps.blocks_target = ((size_t)s.pos0 + (size_t)(att_done + want) * 4 + MT_N - 1) / MT_N;
+        if (ps.blocks_target > s.cap_blocks) {
+            size_t cap = s.cap_blocks;
+            while (cap < ps.blocks_target) cap *= 2;
+            uint32_t* nb = (uint32_t*)realloc(s.blocks, cap * MT_N * sizeof(uint32_t));
+            if (!nb) { rc = -1; break; }
+            s.blocks = nb;
+            s.cap_blocks = cap;
         }
-        /* exclusive prefix; the chunk in which the last needed pair falls ends the batch */
-        int64_t run = acc_done, last_chunk = nch - 1;
-        int finished = 0;
-        for (int64_t c = 0; c < nch; ++c) {
-            const int64_t k = counts[c];
-            counts[c] = run;
-            run += k;
-            if (!finished && run >= pairs) { last_chunk = c; finished = 1; }
+        int64_t* np_ = (int64_t*)realloc(pref, (size_t)nch * sizeof(int64_t));
+        if (!np_) { rc = -1; break; }
+        pref = np_;
+        for (int64_t c = 0; c < nch; ++c) pref[c] = -1;
+        ps.s = &s; ps.out = out; ps.scale = scale; ps.ncol = ncol; ps.n = n; ps.done = done;
+        ps.pairs = pairs; ps.acc0 = acc_done; ps.att0 = att_done; ps.nch = nch; ps.CH = CH;
+        ps.scratch = g_scratch;
+        ps.pref = pref; ps.blocks_ready = s.n_blocks; ps.next_chunk = 0; ps.end_attempt = -1;
+#pragma omp parallel num_threads(threads)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num();
+#else
+            const int tid = 0;
+#endif
+            HS_PIN_BEGIN(&node_cpus, pin);
+            if (tid == 0) pass_generate(&ps);
+            pass_work(&ps, tid);
+            HS_PIN_END();
         }
-        counts[nch] = run;
-        int64_t end_attempt = -1;  /* index (within the batch) of the attempt that supplies the last pair */
-#pragma omp parallel for schedule(static) num_threads(g_threads)
-        for (int64_t c = 0; c <= last_chunk; ++c) {
-            int64_t k = counts[c];
-            const uint32_t* wc = w + (size_t)c * CH * 4;
-            for (int64_t a = 0; a < CH && k < pairs; ++a) {
-                double f, g;
-                if (attempt(wc + a * 4, &f, &g)) {
-                    const int64_t o = done + 2 * k;
-                    out[o] = SCALED(o, f);
-                    if (o + 1 < n) out[o + 1] = SCALED(o + 1, g);
-                    else { st->gauss = g; }  /* only the very last pair of an odd request lands here */
-                    ++k;
-                    if (k == pairs) {
-#pragma omp atomic write
-                        end_attempt = c * CH + a;
-                    }
-                }
-            }
-        }
-        if (finished) {
-            att_done += end_attempt + 1;
+        if (ps.end_attempt >= 0) {
+            att_done += ps.end_attempt + 1;
             acc_done = pairs;
+            last_second = ps.last_second;
         } else {
             att_done += want;
-            acc_done = run;
+            acc_done = pref[nch - 1];
         }
     }
     if (rc != 0) {  /* out of memory: leave the state as it was found */
         st->has_gauss = had_gauss;
         st->gauss = old_gauss;
-    }
-    if (rc == 0) {
+    } else {
         const int odd = ((n - done) & 1) != 0;
-        const double cached = st->gauss;
+        /* the block the end position lies in may not exist yet when the pass stopped the generator early:
+         * cannot happen -- the finishing chunk waited for all of its blocks -- but the position just past
+         * the last block needs none (pos = 624 of the block before) */
         stream_state_after(&s, (size_t)att_done * 4, st);
         st->has_gauss = odd;
-        st->gauss = odd ? cached : 0.0;
+        st->gauss = odd ? last_second : 0.0;
     }
-#undef SCALED
-    free(counts);
+    free(pref);
     stream_free(&s);
     return rc;
 }

@@ -1,3 +1,7 @@
+/* Phase timing of csrc/hoststream.c on the host: sequential MT19937 blocks, tempering, and the whole
+ * standard_normal call for several thread counts.
+ *   gcc -O3 -fopenmp -ffp-contract=off -o /tmp/hsp tools/ubench/hoststream_phases.c -lm && /tmp/hsp */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -8,10 +12,9 @@ static double now(){struct timespec t; clock_gettime(CLOCK_MONOTONIC,&t); return
 int main(){
   hs_state st; memset(&st,0,sizeof st); for(int i=0;i<624;i++) st.key[i]=1812433253u*i+12345u; st.pos=624;
   int64_t n=128*65536; double* out=malloc(n*8);
-  for(int rep=0;rep<3;rep++){
+  for(int rep=0;rep<2;rep++){
     hs_stream s; stream_init(&s,&st);
     double t0=now(); size_t need=(size_t)(n/2/0.785*1.03)*4;
-    /* blocks only */
     size_t have=s.n_blocks*MT_N - s.pos0; size_t more=(need-have+MT_N-1)/MT_N;
     s.cap_blocks=s.n_blocks+more+1; s.blocks=realloc(s.blocks,s.cap_blocks*MT_N*4);
     double t1=now();
@@ -21,8 +24,17 @@ int main(){
     double t3=now();
     printf("alloc %.1f ms, mt blocks %.1f ms (%.2f ns/word), temper+alloc %.1f ms\n",(t1-t0)*1e3,(t2-t1)*1e3,(t2-t1)*1e9/(more*624.0),(t3-t2)*1e3);
     stream_free(&s);
-    double t4=now(); pbbi_host_standard_normal(&st,out,n); double t5=now();
-    printf("full call %.1f ms, threads %d\n",(t5-t4)*1e3,pbbi_host_threads());
+  }
+  int ths[]={1,2,4,8,12,16,24,32,64};
+  for(int k=0;k<9;k++){
+    pbbi_host_set_threads(ths[k]);
+    double best=1e9;
+    for(int rep=0;rep<4;rep++){ double t4=now(); pbbi_host_standard_normal(&st,out,n); double t5=now(); if(t5-t4<best) best=t5-t4; }
+    printf("threads %2d: full call best of 4 %.1f ms\n",ths[k],best*1e3);
+#ifdef HS_PROFILE
+    if(ths[k]==8||ths[k]==16){ for(int t=0;t<ths[k];t++){ printf("  t%02d gen %.1f waitblk %.1f count %.1f waitpref %.1f write %.1f chunks %.0f (ms, sum of 4 calls)\n",t,hs_prof[t][0]*1e3,hs_prof[t][1]*1e3,hs_prof[t][2]*1e3,hs_prof[t][3]*1e3,hs_prof[t][4]*1e3,hs_prof[t][5]); } }
+    memset(hs_prof,0,sizeof hs_prof);
+#endif
   }
   return 0;
 }
