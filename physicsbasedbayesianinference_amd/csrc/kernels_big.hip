@@ -490,6 +490,178 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
     }
 }
 
+// ---- fp32, wide block tile -------------------------------------------------------------------------
+// Interior of a zero-mean fp32 problem (config C5's every block): the same GEMM + fused epilogue on a
+// 256-row block tile.  What limits k_big_gemm at 128 x 128 is the operand traffic, not the matrix pipe
+// (ablation, DESIGN.md 4.4: the tile fills cost 11 %, the LDS operand reads 6 %): per MFMA a 128 x 128
+// block moves 1/64 of a tile row pair from L2 into LDS and a 64 x 64 wave tile reads one operand value
+// per MFMA.  Here a block is BM x BN = 256 x (128 | 256) and a wave 128 x (64 | 128): 0.75x / 0.5x the
+// fill bytes and 0.75x / 0.5x the operand reads per MFMA.  Tiles arrive by LDS-DMA only (one 1-KiB wave
+// instruction per 256-float row), epilogue staged through the (then free) operand buffers 32 rows per
+// wave row at a time.  Anything that is not a whole aligned tile goes to k_big_gemm.
+template <int WAVES_M_, int WAVES_N_, int TN_, int BK_, int MINW_>
+struct WideCfg {
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = 4, TN = TN_, BK = BK_, MINW = MINW_;
+    static constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
+    static constexpr int CS = BN + 4;                       // padded row stride of the staged tile
+    static constexpr int RGS = NTHR / (BN / 4);             // row groups of the epilogue's read phase
+    static constexpr size_t LDS_MAIN = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    static constexpr size_t LDS_EPI = ((size_t)WAVES_M * 32 * CS + (size_t)RGS * BN) * sizeof(float);
+    static constexpr size_t LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+    static_assert(TM * 32 == 128, "one wave row = one 128-row slab of xg_part");
+    static_assert(BM == 256 && (BN == 128 || BN == 256), "row = 1 KiB (A) and 512 B / 1 KiB (B)");
+};
+
+template <class C, int EPI>
+__global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<float> prm) {
+    constexpr int BMW = C::BM, BNW = C::BN, BK = C::BK, TM = C::TM, TN = C::TN, NW = C::NW;
+    extern __shared__ __attribute__((aligned(16))) char smem_big[];
+    float* const As = reinterpret_cast<float*>(smem_big);            // [2][BK][BMW]
+    float* const Bs = As + 2 * BK * BMW;                             // [2][BK][BNW]
+    // (readfirstlane: the wave index is uniform, and an LDS-DMA destination the compiler cannot prove
+    // uniform costs a waterfall loop per instruction)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wmi = wave / C::WAVES_N, wm = wmi * (TM * 32), wn = (wave % C::WAVES_N) * (TN * 32);
+    const int n_tiles_m = prm.D / BMW;
+    const int bm = blockIdx.x % n_tiles_m, bn = blockIdx.x / n_tiles_m;
+    const int i0 = bm * BMW;
+    const int64_t n0 = (int64_t)bn * BNW;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.PT + i0), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.q + n0), 0, 0xFFFFFFF0u, 0x00020000);
+    constexpr int LPR_B = BNW / 4, RPI_B = 64 / LPR_B;   // lanes per B row, B rows per wave instruction
+    const uint32_t vA = 16u * (uint32_t)lane;
+    const uint32_t vB = (uint32_t)(lane / LPR_B) * (uint32_t)prm.ldq * 4u + 16u * (uint32_t)(lane % LPR_B);
+    auto dma_tiles = [&](int k0, int buf) {
+#pragma unroll
+        for (int j = 0; j < BK / NW; ++j) {  // A: one row per instruction
+            const int row = wave + NW * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void*)(As + (buf * BK + row) * BMW), 16, vA,
+                                                     (uint32_t)(k0 + row) * (uint32_t)prm.DPAD * 4u, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / RPI_B / NW; ++j) {
+            const int row = RPI_B * (wave + NW * j);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void*)(Bs + (buf * BK + row) * BNW), 16, vB,
+                                                     (uint32_t)(k0 + row) * (uint32_t)prm.ldq * 4u, 0, 0);
+        }
+    };
+
+    v16f32 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int nk = prm.D / BK;
+    dma_tiles(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) dma_tiles((t + 1) * BK, cur ^ 1);  // lands under the MFMAs
+        // operands of K-step s+1 are read before the TM*TN MFMAs of K-step s issue (see MmaF32::tile)
+        const float* ap = As + (cur * BK + kh) * BMW + wm + r32;
+        const float* bp = Bs + (cur * BK + kh) * BNW + wn + r32;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int x = 0; x < TM; ++x) a[0][x] = ap[32 * x];
+#pragma unroll
+        for (int x = 0; x < TN; ++x) b[0][x] = bp[32 * x];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int c = s & 1, nx = c ^ 1;
+            if (s + 1 < BK / 2) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x) a[nx][x] = ap[2 * (s + 1) * BMW + 32 * x];
+#pragma unroll
+                for (int x = 0; x < TN; ++x) b[nx][x] = bp[2 * (s + 1) * BNW + 32 * x];
+            }
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][ta], b[c][tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: TM passes; in pass ta every wave stages its row tile ta (32 rows x TN*32 columns),
+    // then the block reads the WAVES_M*32 staged rows back row-major, 16 bytes per access
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int CS = C::CS, RGS = C::RGS, CPRW = BNW / 4;
+    float* const Cst = reinterpret_cast<float*>(smem_big);   // [WAVES_M*32][CS]
+    float* const red2 = Cst + C::WAVES_M * 32 * CS;           // [RGS][BNW]
+    const int cg = tid % CPRW, rg = tid / CPRW;
+    const int64_t n = n0 + 4 * cg;
+    f4 xg4[C::WAVES_M];
+#pragma unroll
+    for (int w = 0; w < C::WAVES_M; ++w) xg4[w] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 mi4 = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (EPI == EPI_KDK)
+        if (prm.minv) mi4 = *reinterpret_cast<const f4*>(prm.minv + n);
+#pragma unroll
+    for (int ta = 0; ta < TM; ++ta) {
+        if (ta) __syncthreads();  // the previous pass has been read
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)  // C/D map of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                Cst[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CS + wn + 32 * tb + r32] = acc[ta][tb][r];
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < C::WAVES_M; ++w) {
+#pragma unroll 4
+            for (int pss = 0; pss < 32 / RGS; ++pss) {
+                const int rr = pss * RGS + rg;                   // row of wave row w's staged tile
+                const int i = i0 + w * (TM * 32) + ta * 32 + rr;
+                const f4 g = *reinterpret_cast<const f4*>(&Cst[(w * 32 + rr) * CS + 4 * cg]);
+                const f4 qv = *reinterpret_cast<const f4*>(prm.q + (int64_t)i * prm.ldq + n);
+                xg4[w] += qv * g;
+                if constexpr (EPI == EPI_EVAL) {
+                    if (prm.grad_out) *reinterpret_cast<f4*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;
+                } else {
+                    const int64_t o = (int64_t)i * prm.ldw + n;
+                    const f4 v = *reinterpret_cast<const f4*>(prm.vh + o) + (-(g * mi4)) * prm.hk;  // kick
+                    *reinterpret_cast<f4*>(prm.vh + o) = v;
+                    if (prm.q_next) *reinterpret_cast<f4*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                }
+            }
+        }
+    }
+    if (prm.xg_part) {
+#pragma unroll
+        for (int w = 0; w < C::WAVES_M; ++w) {
+            __syncthreads();
+            *reinterpret_cast<f4*>(&red2[rg * BNW + 4 * cg]) = xg4[w];
+            __syncthreads();
+            if (tid < BNW) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RGS; ++r) s += red2[r * BNW + tid];
+                prm.xg_part[(size_t)(i0 / BM + w) * prm.N + n0 + tid] = s;
+            }
+        }
+    }
+}
+
+#ifndef PBBI_BIG_WIDE
+#define PBBI_BIG_WIDE 3   // 0: off; 1: 256 x 256, 8 waves of 128 x 64; 2: 256 x 256, 4 waves of 128 x 128; 3: 256 x 128, 4 waves of 128 x 64, two blocks per CU
+#endif
+#if PBBI_BIG_WIDE == 1
+typedef WideCfg<2, 4, 2, 32, 1> Wide;
+#elif PBBI_BIG_WIDE == 2
+typedef WideCfg<2, 2, 4, 32, 1> Wide;
+#elif PBBI_BIG_WIDE == 3
+typedef WideCfg<2, 2, 2, 16, 2> Wide;
+#endif
+
 // ---- elementwise helpers ---------------------------------------------------------------------------
 // column sums over row blocks: part[rb][n] = sum_{d in block rb} f(a[d][n]) with f = square.
 template <typename T>
@@ -631,6 +803,32 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
                    xg_part, N, ldq, ldw, ldg, pot->D, pot->DPAD_big, hk, h, 0};
     static const bool no_dma = (getenv("PBBI_BIG_NO_DMA") != nullptr);
     prm.no_dma = no_dma ? 1 : 0;
+#if PBBI_BIG_WIDE
+    if constexpr (sizeof(T) == 4) {
+        // the wide-tile kernel: whole aligned tiles of a zero-mean problem only (PBBI_BIG_TILE=128 forces
+        // the 128 x 128 kernel, for A/B measurements and tests)
+        static const bool narrow = [] { const char* e = getenv("PBBI_BIG_TILE"); return e && atoi(e) == 128; }();
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        bool ok = !narrow && pot->zero_mean && pot->D == pot->DPAD_big && pot->D % Wide::BM == 0 && N % Wide::BN == 0 &&
+                  ldq % 4 == 0 && al16(q) && al16(prm.PT) &&
+                  (int64_t)pot->D * (ldq > pot->D ? ldq : (int64_t)pot->D) * 4 < ((int64_t)1 << 32);
+        if (epi == EPI_EVAL) ok = ok && (!grad_out || (ldg % 4 == 0 && al16(grad_out)));
+        else ok = ok && ldw % 4 == 0 && al16(vh) && (!q_next || al16(q_next)) && (!minv || al16(minv));
+        if (ok) {
+            const unsigned tiles_w = (unsigned)((pot->D / Wide::BM) * (N / Wide::BN));
+            auto gow = [&](auto kernel) -> int {
+                PBBI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wide::LDS));
+                hipLaunchKernelGGL(kernel, dim3(tiles_w), dim3(Wide::NTHR), Wide::LDS, st, prm);
+                return PBBI_OK;
+            };
+            if (int rc = (epi == EPI_EVAL) ? gow(k_big_gemm_wide<Wide, EPI_EVAL>) : gow(k_big_gemm_wide<Wide, EPI_KDK>))
+                return rc;
+            PBBI_HIP(hipGetLastError());
+            return PBBI_OK;
+        }
+    }
+#endif
     const unsigned tiles = (unsigned)((pot->DPAD_big / BM) * ((N + BN - 1) / BN));
     size_t lds = (size_t)4 * Cfg<T>::BK * BM * sizeof(T) + 2 * BN * sizeof(T);
 #ifndef PBBI_BIG_NO_STAGED

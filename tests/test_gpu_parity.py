@@ -637,6 +637,49 @@ def test_c5_shape_fp32_vs_fp64_oracle(P, lib):
     assert np.array_equal(to_numpy(rj).astype(bool)[clear], rej[clear])
 
 
+@pytest.mark.parametrize("method,mass,L", [("Leapfrog", False, 10), ("Leapfrog", True, 5), ("Stormer-Verlet", True, 6)])
+def test_big_wide_tile_fp32_vs_oracle(P, lib, method, mass, L):
+    """k_big_gemm_wide (fp32, zero mean, whole 256-row / 256-chain tiles): D = 512, N = 768 = 2 x 3 block
+    tiles, against the fp64 oracle (2e-4 scaled as at C5's shape; decisions equal where they are not
+    marginal) and against the 128 x 128 kernel, which the same call takes for N - 4 chains."""
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    import torch
+    D, N, h = 512, 768, 0.15
+    Pm, _ = _dense_problem(D, 12)
+    pot = P.GaussianDense(None, precision=Pm, const=0.0, dtype="float32")
+    rs = np.random.RandomState(13)
+    f32 = lambda x: x.astype(np.float32).astype(np.float64)
+    m = f32(1.0 + (np.arange(N) % 3) * 0.5) if mass else None
+    q0, u = f32(rs.standard_normal((D, N))), f32(rs.uniform(size=N))
+    p0 = f32(rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0))
+    mid = 0 if method == "Leapfrog" else 1
+
+    def run(n):
+        qd, pd, ud = (as_device(np.ascontiguousarray(x[..., :n]), 0, np.float32) for x in (q0, p0, u))
+        md = as_device(m[:n], 0, np.float32) if mass else None
+        qo, po = empty((D, n), np.float32, 0), empty((D, n), np.float32, 0)
+        ro, rj = empty((n,), np.float32, 0), empty((n,), np.uint8, 0)
+        lib.call("pbbi_hmc_iter", pot.handle, mid, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+                 md.data_ptr() if mass else None, qo.data_ptr(), po.data_ptr(), ro.data_ptr(), rj.data_ptr(),
+                 n, n, h, L, 1, stream_ptr(0))
+        torch.cuda.synchronize()
+        return (to_numpy(qo).astype(np.float64), to_numpy(po).astype(np.float64),
+                to_numpy(ro).astype(np.float64), to_numpy(rj).astype(bool))
+
+    qw, pw, rw, jw = run(N)
+    qr, pr = q0.copy(), p0.copy()
+    ratio, rej = orc.hmc_iter(orc.pot_gauss_dense(np.zeros(D), Pm), method, qr, pr, u, m, h, L)
+    assert scaled_err(qw, qr) <= 2e-4 and scaled_err(pw, pr) <= 2e-4
+    clear = np.abs(np.log(u) - np.minimum(0.0, np.log(ratio))) > 1e-2
+    assert clear.sum() > N // 2 and np.array_equal(jw[clear], rej[clear])
+    assert 0 < rej.sum() < N
+    qn, pn, rn, jn = run(N - 4)                       # ragged: the 128 x 128 kernel
+    same = jw[:N - 4] == jn
+    assert same.mean() > 0.99
+    assert scaled_err(qw[:, :N - 4][:, same], qn[:, same]) <= 2e-5
+    assert np.max(np.abs(np.log(rw[:N - 4]) - np.log(rn))) < 5e-3
+
+
 # ------------------------------------------------------------------ two-lanes-per-chain Rosenbrock kernel
 @pytest.mark.parametrize("D,N,mass,compat", [(32, 1000, False, True), (32, 77, True, False),
                                              (20, 130, True, True), (17, 33, False, True),
