@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
     T (*Bs)[BK * BN] = reinterpret_cast<T (*)[BK * BN]>(smem_big + 2 * BK * BM * sizeof(T));  // [2]
     T (*red)[BN] = reinterpret_cast<T (*)[BN]>(smem_big + 4 * BK * BM * sizeof(T));    // [2]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform
     const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * Cfg<T>::WTN;
     const int n_tiles_m = prm.DPAD / BM;
     const int bm = blockIdx.x % n_tiles_m, bn = blockIdx.x / n_tiles_m;  // a P^T panel's tiles are
@@ -499,25 +499,30 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
 // fill bytes and 0.75x / 0.5x the operand reads per MFMA.  Tiles arrive by LDS-DMA only (one 1-KiB wave
 // instruction per 256-float row), epilogue staged through the (then free) operand buffers 32 rows per
 // wave row at a time.  Anything that is not a whole aligned tile goes to k_big_gemm.
-template <int WAVES_M_, int WAVES_N_, int TN_, int BK_, int MINW_>
+template <int WAVES_M_, int WAVES_N_, int TN_, int BK_, int MINW_, int NST_ = 2>
 struct WideCfg {
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = 4, TN = TN_, BK = BK_, MINW = MINW_;
+    static constexpr int NST = NST_;                        // operand stages in LDS (tiles in flight: NST - 1)
     static constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
     static constexpr int CS = BN + 4;                       // padded row stride of the staged tile
     static constexpr int RGS = NTHR / (BN / 4);             // row groups of the epilogue's read phase
-    static constexpr size_t LDS_MAIN = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    static constexpr size_t LDS_MAIN = (size_t)NST * BK * (BM + BN) * sizeof(float);
     static constexpr size_t LDS_EPI = ((size_t)WAVES_M * 32 * CS + (size_t)RGS * BN) * sizeof(float);
     static constexpr size_t LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
     static_assert(TM * 32 == 128, "one wave row = one 128-row slab of xg_part");
     static_assert(BM == 256 && (BN == 128 || BN == 256), "row = 1 KiB (A) and 512 B / 1 KiB (B)");
 };
 
+#ifndef PBBI_WIDE_ABLATE
+#define PBBI_WIDE_ABLATE 0
+#endif
 template <class C, int EPI>
 __global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<float> prm) {
     constexpr int BMW = C::BM, BNW = C::BN, BK = C::BK, TM = C::TM, TN = C::TN, NW = C::NW;
     extern __shared__ __attribute__((aligned(16))) char smem_big[];
-    float* const As = reinterpret_cast<float*>(smem_big);            // [2][BK][BMW]
-    float* const Bs = As + 2 * BK * BMW;                             // [2][BK][BNW]
+    constexpr int NST = C::NST;
+    float* const As = reinterpret_cast<float*>(smem_big);            // [NST][BK][BMW]
+    float* const Bs = As + NST * BK * BMW;                           // [NST][BK][BNW]
     // (readfirstlane: the wave index is uniform, and an LDS-DMA destination the compiler cannot prove
     // uniform costs a waterfall loop per instruction)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -558,12 +563,18 @@ __global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<floa
 
     const int r32 = lane & 31, kh = lane >> 5;
     const int nk = prm.D / BK;
-    dma_tiles(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NST - 1 tiles in flight; a wave waits for its own share of the oldest one (its DMA instructions
+    // retire in order: vmcnt <= the instructions of the younger tiles) and the barrier publishes all shares
+    constexpr int DMA_PER_TILE = BK / NW + BK / RPI_B / NW;
+#pragma unroll
+    for (int pre = 0; pre < NST - 1; ++pre) dma_tiles(pre * BK, pre);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DMA_PER_TILE) : "memory");
     __syncthreads();
+    int cur = 0, nxt = NST - 1;  // buffer of tile t, buffer tile t + NST - 1 goes to
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) dma_tiles((t + 1) * BK, cur ^ 1);  // lands under the MFMAs
+#if !(PBBI_WIDE_ABLATE & 1)   // (bit 0: no tile fills after the prologue -- timing experiment, wrong results)
+        if (t + NST - 1 < nk) dma_tiles((t + NST - 1) * BK, nxt);  // lands under the MFMAs
+#endif
         // operands of K-step s+1 are read before the TM*TN MFMAs of K-step s issue (see MmaF32::tile)
         const float* ap = As + (cur * BK + kh) * BMW + wm + r32;
         const float* bp = Bs + (cur * BK + kh) * BNW + wn + r32;
@@ -575,7 +586,11 @@ __global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<floa
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int c = s & 1, nx = c ^ 1;
+#if PBBI_WIDE_ABLATE & 2   // (bit 1: operands read once per tile -- timing experiment, wrong results)
+            if (s == 0) {
+#else
             if (s + 1 < BK / 2) {
+#endif
 #pragma unroll
                 for (int x = 0; x < TM; ++x) a[nx][x] = ap[2 * (s + 1) * BMW + 32 * x];
 #pragma unroll
@@ -588,10 +603,26 @@ __global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<floa
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][ta], b[c][tb], acc[ta][tb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NST > 2 && t + NST - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
 
+#if PBBI_WIDE_ABLATE & 4   // (bit 2: no epilogue -- timing experiment, wrong results; one store keeps the MFMAs alive)
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[a][b][r];
+        if (keep == 12345.678f) prm.vh[tid] = keep;
+        return;
+    }
+#endif
     // ---- epilogue: TM passes; in pass ta every wave stages its row tile ta (32 rows x TN*32 columns),
     // then the block reads the WAVES_M*32 staged rows back row-major, 16 bytes per access
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -660,6 +691,10 @@ typedef WideCfg<2, 4, 2, 32, 1> Wide;
 typedef WideCfg<2, 2, 4, 32, 1> Wide;
 #elif PBBI_BIG_WIDE == 3
 typedef WideCfg<2, 2, 2, 16, 2> Wide;
+#elif PBBI_BIG_WIDE == 4   // 3 with three operand stages (72 KiB per block)
+typedef WideCfg<2, 2, 2, 16, 2, 3> Wide;
+#elif PBBI_BIG_WIDE == 5   // 3 with four stages of 8 rows (48 KiB per block)
+typedef WideCfg<2, 2, 2, 8, 2, 4> Wide;
 #endif
 
 // ---- elementwise helpers ---------------------------------------------------------------------------
