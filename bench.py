@@ -299,7 +299,7 @@ def bench_c5(args):
         "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C5: d=4096 dense precision, {N} chains, fp32, L=10, h=0.05",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "mfma", "kernel": "k_big_gemm<float, KDK> x (L+1) per iteration",
+        "roofline": {"bound": "mfma", "kernel": "k_big_gemm_wide<256x128x16, KDK> x (L+1) per iteration",
                      "achieved": flops_it / it_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops_it / it_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flops_per_iteration": flops_it, "iteration_ms": it_s * 1e3}}
@@ -483,7 +483,14 @@ def main():
     ap.add_argument("--potential", default="rosenbrock", choices=["rosenbrock", "diag"],
                     help="--workload stream: potential")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
+    ap.add_argument("--rng", default="philox", choices=["philox", "numpy"],
+                    help="--workload c2 --rng numpy = --workload parity: C2 through the class API's default "
+                         "mode (the reference's NumPy stream drawn on the host)")
     args = ap.parse_args()
+    if args.rng == "numpy":
+        if args.workload not in ("c2", "parity"):
+            ap.error("--rng numpy goes with --workload c2")
+        args.workload = "parity"
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1:
         ap.error("--steps >= 1, --warmup >= 0, --gpus >= 1")
 

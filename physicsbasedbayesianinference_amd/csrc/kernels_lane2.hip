@@ -163,24 +163,31 @@ struct Ros2 {
         return (s + xchg(s)) * inv_s + cst;
     }
 
-    // U(q), valid in the half-1 lanes: the two sequential sums continue half 0's prefixes.
+    // U(q), valid in the half-1 lanes: the two sequential sums continue half 0's prefixes.  The terms
+    // (t_j, b t_j, a - q_j) are formed once; only the two dependent summation chains run twice (from 0
+    // for half 0's prefix, then continued from it for half 1).
     __device__ __forceinline__ double U(const double (&q)[DL]) const {
         const double q_ext = xchg(q[0]);
+        double t[DL], bt[DL], r[DL];
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
+            t[j] = fma(-q[j], q[j], qn);
+            bt[j] = b * t[j];
+            r[j] = a - q[j];
+        }
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {  // pass 0: from 0 (half 0's prefix); pass 1: continued
             double r1 = pass ? xchg(s1) : 0.0, r2 = pass ? xchg(s2) : 0.0;
 #pragma unroll
             for (int j = 0; j < DL; ++j) {
-                const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
-                const double t = fma(-q[j], q[j], qn);
-                const double n1 = fma(b * t, t, r1);
+                const double n1 = fma(bt[j], t[j], r1);
                 r1 = has_next(j) ? n1 : r1;
             }
 #pragma unroll
             for (int j = 0; j < DL; ++j) {
-                const double r = a - q[j];
-                const double n2 = fma(r, r, r2);
+                const double n2 = fma(r[j], r[j], r2);
                 r2 = has_next(j) ? n2 : r2;
             }
             if (pass == 0 || half) { s1 = r1; s2 = r2; }
@@ -189,14 +196,17 @@ struct Ros2 {
     }
 };
 
-// sum_d p_d^2 in oracle order, valid in the half-1 lanes
+// sum_d p_d^2 in oracle order, valid in the half-1 lanes (squares formed once, summed twice)
 __device__ __forceinline__ double pp_seq(const double (&p)[DL], int half) {
+    double sq[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) sq[j] = p[j] * p[j];
     double s = 0.0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         double r = pass ? xchg(s) : 0.0;
 #pragma unroll
-        for (int j = 0; j < DL; ++j) r += p[j] * p[j];
+        for (int j = 0; j < DL; ++j) r += sq[j];
         if (pass == 0 || half) s = r;
     }
     return s;
