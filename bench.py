@@ -400,7 +400,15 @@ def bench_c2(args, rank, world, local_rank):
     kernel_ss = dev_ms_s * 1e-3 / K
     flops_launch = flops_per_step_chain(D, L) * L * N
     bytes_launch = bytes_per_step_chain(D, L) * L * N
-    traffic, traffic_src = profile_json("r*_pmc.json", "k_dense_hmc_hbm_bytes_per_launch")
+    traffic, traffic_src = profile_json("r*_pmc.json", "k_dense_hmc_hbm_bytes_per_iteration")
+    # pbbi_hmc_run carries the gradient of the chain's position from one iteration to the next (an
+    # accepted chain starts from the point whose gradient the last mat-vec just formed, a rejected one from
+    # the point it started at) and covers up to PBBI_DENSE_FUSE iterations per launch: L mat-vecs per
+    # iteration are EXECUTED where SURVEY 8d's algorithmic figure counts L + 1.  Both rates are reported.
+    carried = os.environ.get("PBBI_NO_CARRY") is None
+    fuse = max(1, int(os.environ.get("PBBI_DENSE_FUSE", "32"))) if carried else 1
+    flops_exec = (2.0 * D * D * (L if carried else L + 1) + 11.0 * D * L + 8.0 * D) * N
+    bytes_exec = bytes_launch + (2.0 * D * 8 * N if carried else 0.0)  # g read + g(q_new) written
     out = {
         "metric": "leapfrog-steps*chains/sec (node); d=128 Gaussian, ensemble=65536",
         "value": K * L * total_chains / t,
@@ -423,14 +431,23 @@ def bench_c2(args, rank, world, local_rank):
                    "stepSize": STEP, "parallelism": f"ensemble-sharded x{world}",
                    "accept_rate": accept},
         "roofline": {
-            "bound": "mfma", "kernel": "k_dense_hmc<8, full, hmc, zero-mean>",
+            "bound": "mfma",
+            "kernel": "k_dense_hmc<8, full, hmc, zero-mean" + (", carried gradient, fused iterations>" if carried else ">"),
+            # per ITERATION (one step of this bench); a launch covers iterations_per_launch of them
             "achieved": flops_launch / kernel_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flops_launch / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "frac_steady": flops_launch / kernel_ss / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "achieved_executed": flops_exec / kernel_s / 1e12,
+            "frac_executed": flops_exec / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "note": ("frac = SURVEY 8d's algorithmic flops (L + 1 gradient mat-vecs per iteration) / time / peak; "
+                     "frac_executed counts the L mat-vecs the kernel performs (the gradient at the chain's "
+                     "position is carried between iterations, bit-identical samples)") if carried else None,
             "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_flops_per_launch": flops_launch,
-            "algorithmic_bytes_per_launch": bytes_launch,
-            "launch_ms": kernel_s * 1e3, "launch_ms_steady": kernel_ss * 1e3,
+            "algorithmic_flops_per_iteration": flops_launch, "algorithmic_flops_per_launch": flops_launch * fuse,
+            "algorithmic_bytes_per_iteration": bytes_launch, "algorithmic_bytes_per_launch": bytes_launch * fuse,
+            "executed_flops_per_iteration": flops_exec, "executed_bytes_per_iteration": bytes_exec,
+            "iteration_ms": kernel_s * 1e3, "iterations_per_launch": fuse,
+            "launch_ms": kernel_s * 1e3 * fuse, "launch_ms_steady": kernel_ss * 1e3 * fuse,
             "hbm_algorithmic_GBs": bytes_launch / kernel_s / 1e9,
             "hbm_frac_of_8TBs": bytes_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
         },

@@ -38,6 +38,8 @@
 #include <vector>
 
 #include "pbbi_buf.h"
+#include <type_traits>
+
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
 
@@ -110,6 +112,14 @@ struct DensePrm {
     uint64_t seed, iter, chain0;
     const int32_t* steps_in;  // PBBI_PER_CHAIN_STEPS, uploaded mode (nullptr: L)
     int32_t* steps_out;
+    // gradient carried across the iterations of a run (CARRY, see k_dense_hmc)
+    double* carry_g;            // [2][D][N]
+    uint8_t* carry_sel;         // [N]: which of the two slabs holds g at the chain's current position
+    uint32_t carry_slab_bytes;  // D*N*8
+    // several iterations of a run in one launch (FUSE, see k_dense_hmc; IterArgs::fuse_*)
+    int fuse_S, fuse_wrap2;
+    int64_t fuse_slab0, fuse_slab;
+    double* fuse_q_base;
 };
 
 template <int NT>
@@ -513,8 +523,19 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 // (drift step 0, kick 0) instead of a branch around the register arrays, its last kick is its own
 // half kick, and x.g for H_new is taken at the wave's last step, where every frozen chain still
 // holds its final position.
-template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, bool DYN = false>
+// CARRY (MODE 0, Leapfrog, inside pbbi_hmc_run): the last mat-vec of an iteration is g(q_new), and the
+// next iteration starts from q_new (accepted) or from the point this one started from (rejected) -- in
+// both cases a gradient that already exists.  It is kept in HBM, two slabs per chain and one byte that
+// says which is current: an iteration reads g from the current slab instead of forming it (L instead of
+// L + 1 mat-vecs), writes g(q_new) to the other one and flips the byte when it accepts.  CARRY = 1 is the
+// first iteration of a run (forms g(q_0), stores it as slab 0), CARRY = 2 every later one.  The values
+// are the ones the mat-vec would produce again -- same instructions on the same q -- so a run's samples
+// do not change by a bit.
+template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, bool DYN = false, int CARRY = 0,
+          bool FUSE = false>
 __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
+    static_assert(CARRY == 0 || (MODE == 0 && METHOD == PBBI_LEAPFROG && !DYN), "carry: plain Leapfrog iterations");
+    static_assert(!FUSE || CARRY == 2, "a fused launch continues a run whose first iteration stored g(q_0)");
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
     constexpr int NPASS = NT >= 4 ? 2 : 1;  // row passes per mat-vec
@@ -565,9 +586,47 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     const double m = prm.mass ? prm.mass[n0 + cc] : 1.0;
     const double minv = prm.mass ? 1.0 / m : 1.0;
     const bool rng = (MODE == 0) && prm.rng;
+    // carried gradient: slabs [2][D][N] with the leading stride N; this lane's offset into the current one
+    [[maybe_unused]] const uint32_t ld_g = 8u * (uint32_t)prm.N, s4g = 4u * ld_g;
+    [[maybe_unused]] uint32_t vg_cur = 0, vg_new = 0;
+    [[maybe_unused]] uint32_t csel = 0;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t gbuf = buf_make(CARRY ? prm.carry_g + n0 : nullptr);
+    if constexpr (CARRY != 0) {
+        if constexpr (CARRY == 2) csel = prm.carry_sel[n0 + cc];
+    }
+    double q[KS];
+    if constexpr (FUSE) {  // the chain's position stays in these registers for the whole launch
+#pragma unroll
+        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+    }
+    // FUSE: prm.fuse_S consecutive iterations of the run in this launch (the host passes ldn_in == ldn_out:
+    // every iteration after a run's first reads the previous position slab).  Iteration kf draws with
+    // counter iter + kf, re-reads a rejected chain's position from slab (slab0 + kf - 1), writes position
+    // slab (slab0 + kf) of fuse_q_base (modulo 2 for a burn-in's two scratch slabs) and momentum / ratio /
+    // decision rows kf.  Waves that share a SIMD drift apart, so one's draw and stores run under the other's
+    // MFMAs; P is staged once per launch and q is never re-read while the chain keeps accepting.
+    const int nfuse = FUSE ? prm.fuse_S : 1;
+#pragma nounroll
+    for (int kf = 0; kf < nfuse; ++kf) {
+    const uint64_t iter_k = prm.iter + (uint64_t)kf;
+    double* const ratio_k = (FUSE && prm.ratio_out) ? prm.ratio_out + (int64_t)kf * prm.N : prm.ratio_out;
+    uint8_t* const reject_k = (FUSE && prm.reject_out) ? prm.reject_out + (int64_t)kf * prm.N : prm.reject_out;
+    __amdgpu_buffer_rsrc_t qin_k = qin, qout_k = qout, pout_k = pout;
+    if constexpr (FUSE) {
+        const int64_t s_out = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf) & 1) : prm.fuse_slab0 + kf;
+        const int64_t s_prev = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf - 1) & 1) : prm.fuse_slab0 + kf - 1;
+        if (kf > 0) qin_k = buf_make(prm.fuse_q_base + s_prev * prm.fuse_slab + n0);
+        qout_k = buf_make(prm.fuse_q_base + s_out * prm.fuse_slab + n0);
+        pout_k = buf_make(prm.p_out + (prm.p_out ? (int64_t)kf * prm.fuse_slab : 0) + n0);
+    }
+    if constexpr (CARRY != 0) {
+        const uint32_t vg0 = (uint32_t)g * ld_g + 8u * (uint32_t)cc;
+        vg_cur = vg0 + (csel ? prm.carry_slab_bytes : 0u);
+        vg_new = vg0 + (csel ? 0u : prm.carry_slab_bytes);
+    }
 
     // ---- momentum: one Philox block per 4 rows (RNG mode) or the uploaded p_in, then q
-    double q[KS], vh[KS];
+    double vh[KS];
     v4f64 acc[NTP];
     if (rng) {
         const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
@@ -575,7 +634,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
 #pragma unroll
         for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g, slot = 0..3
             draw_t z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((k << 2) | g), z);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl)
                 vh[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? (double)z[sl] * pstd : 0.0;
@@ -584,7 +643,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
             // non-compat: a rejected chain reports its drawn momentum; park the draw in the slab
             // now (accepted chains overwrite it below) rather than regenerate it later.
 #pragma unroll
-            for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, vh[s]);
+            for (int s = 0; s < KS; ++s) store_elem<FULL>(pout_k, vout, s4out, s, g, D, vh[s]);
         }
     } else {
         const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
@@ -592,8 +651,10 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
     }
     STAMP(2);
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+    }
     __builtin_amdgcn_sched_barrier(0);
     double pp = 0.0;
 #pragma unroll
@@ -606,11 +667,36 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
 
     // ---- g(q_0) in row passes: U(q_old) and the first half kick
     const double ck = h * minv, ckh = 0.5 * ck;  // kick coefficients h/m and h/(2m)
-    matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+    // rows of pass PASS of the carried gradient <-> acc (element s = 4*(PASS*NTP + t) + r, like q[s])
+    auto carry_load = [&](auto pass_c) {
+        constexpr int PASS = decltype(pass_c)::value;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[t][r] = load_elem<FULL>(gbuf, vg_cur, s4g, ld_g, 4 * (PASS * NTP + t) + r, g, D);
+    };
+    auto carry_store = [&](auto pass_c, uint32_t voff) {
+        constexpr int PASS = decltype(pass_c)::value;
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_elem<FULL>(gbuf, voff, s4g, 4 * (PASS * NTP + t) + r, g, D, acc[t][r]);
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if constexpr (CARRY == 2) carry_load(P0{});
+    else matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+    if constexpr (CARRY == 1) carry_store(P0{}, vg_cur);
     double xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
     kick_pass<NT, NTP, 0>(vh, acc, ckh);
     if constexpr (NPASS == 2) {
-        matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+        if constexpr (CARRY == 2) carry_load(P1{});
+        else matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+        if constexpr (CARRY == 1) carry_store(P1{}, vg_cur);
         xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
         kick_pass<NT, NTP, 1>(vh, acc, ckh);
     }
@@ -620,7 +706,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     xg = 0.0;
     int Ln = prm.L, Lw = prm.L;  // this chain's steps, the wave's
     if constexpr (DYN) {
-        if (rng) Ln = rng_steps(prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc), prm.L);
+        if (rng) Ln = rng_steps(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc), prm.L);
         else if (prm.steps_in) Ln = prm.steps_in[n0 + cc];
         Ln = Ln < 1 ? 1 : (Ln > prm.L ? prm.L : Ln);
         Lw = Ln;
@@ -642,11 +728,15 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         STAMP(5 + 2 * j);
         matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, hq);  // drift + g(q_{j+1})
         if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+        if constexpr (CARRY != 0)
+            if (last) carry_store(P0{}, vg_new);  // g(q_new), for the next iteration if this one accepts
         kick_pass<NT, NTP, 0>(vh, acc, cj);
         STAMP(6 + 2 * j);
         if constexpr (NPASS == 2) {
             matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
             if (last && MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+            if constexpr (CARRY != 0)
+                if (last) carry_store(P1{}, vg_new);
             kick_pass<NT, NTP, 1>(vh, acc, cj);
         }
     }
@@ -690,14 +780,14 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         const double newH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
         STAMP(40);
         const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));
-        const double u = rng ? rng_uniform(prm.seed, prm.iter, prm.chain0 + (uint64_t)(n0 + cc))
+        const double u = rng ? rng_uniform(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc))
                              : prm.u_in[n0 + cc];
         const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
         const bool compat = (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
         bool store_p = (prm.p_out != nullptr);
         if (reject) {  // rare: fetch the old point again instead of keeping it in registers
 #pragma unroll
-            for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);  // :175
+            for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin_k, vin, s4in, ld_in, s, g, D);  // :175
             if (compat) {  // :176  p <- oldQ
 #pragma unroll
                 for (int s = 0; s < KS; ++s) vh[s] = q[s];
@@ -711,20 +801,26 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         }
         if (valid) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);  // :178
+            for (int s = 0; s < KS; ++s) store_elem<FULL>(qout_k, vout, s4out, s, g, D, q[s]);  // :178
             if (store_p) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout, vout, s4out, s, g, D, vh[s]);  // :179
+                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout_k, vout, s4out, s, g, D, vh[s]);  // :179
             }
         }
+        if constexpr (CARRY != 0) csel ^= reject ? 0u : 1u;  // accepted: the other slab is current now
         if (valid && g == 0) {
-            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
-            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+            if (ratio_k) ratio_k[n0 + c] = ratio;
+            if (reject_k) reject_k[n0 + c] = reject ? 1 : 0;
             if constexpr (DYN) {
                 if (prm.steps_out) prm.steps_out[n0 + c] = Ln;
             }
+            if constexpr (CARRY != 0 && !FUSE) prm.carry_sel[n0 + c] = (uint8_t)csel;
         }
         STAMP(41);
+    }
+    }  // kf
+    if constexpr (FUSE) {
+        if (valid && g == 0) prm.carry_sel[n0 + c] = (uint8_t)csel;
     }
 }
 
@@ -835,7 +931,7 @@ inline unsigned grid_size(const pbbi_potential* pot, int64_t N) {
 }
 
 int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int64_t N,
-                hipStream_t stream) {
+                hipStream_t stream, int carry_mode = 0) {
     const size_t lds = lds_bytes(pot->DP);
     const dim3 grid(grid_size(pot, N)), block(BLOCK);
     const bool full = (pot->D == pot->DP);
@@ -845,11 +941,24 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
         const bool zmean = pot->zero_mean;
         const bool dyn = prm.mode == 0 && (prm.flags & PBBI_PER_CHAIN_STEPS) != 0;
+        const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
         if (dyn && M_ == 0) {                                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && carry == 1) {                            \
+            if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && F_ && carry == 2 && prm.fuse_S > 1) {   \
+            if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && carry == 2) {                            \
+            if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 2>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 2>), grid2, block2, lds, \
                                stream, prm);                                                      \
         } else if (method == PBBI_LEAPFROG) {                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>, lds)) return rc;    \
@@ -986,7 +1095,46 @@ int dense_hmc_iter(const IterArgs& a) {
     prm.L = a.L; prm.D = a.pot->D; prm.flags = a.flags; prm.rng = a.rng; prm.mode = 0;
     prm.seed = a.seed; prm.iter = a.iter; prm.chain0 = a.chain0;
     prm.steps_in = a.steps_in; prm.steps_out = a.steps_out;
-    return launch_traj(a.pot, a.method, prm, a.N, a.stream);
+    int carry = 0;
+    if (a.carry && a.carry_g && a.carry_sel && dense_carry_applies(a)) {
+        carry = a.carry;
+        prm.carry_g = (double*)a.carry_g;
+        prm.carry_sel = a.carry_sel;
+        prm.carry_slab_bytes = (uint32_t)((uint64_t)a.pot->D * (uint64_t)a.N * 8u);
+    }
+    if (a.fuse_S > 1) {
+        if (carry != 2 || a.ldn_in != a.ldn_out || !a.rng)
+            return pbbi_fail(PBBI_ERR_INVALID, "fused dense iterations continue a carried run (internal)");
+        prm.fuse_S = a.fuse_S;
+        prm.fuse_wrap2 = a.fuse_wrap2;
+        prm.fuse_slab0 = a.fuse_slab0;
+        prm.fuse_slab = (int64_t)a.pot->D * a.N;
+        prm.fuse_q_base = (double*)a.fuse_q_base;
+    }
+    return launch_traj(a.pot, a.method, prm, a.N, a.stream, carry);
+}
+
+// Iterations of a run that ONE launch may cover (k_dense_hmc FUSE): the iterations after the first of a
+// run that carries its gradient, in-kernel draws.  PBBI_DENSE_FUSE=n overrides the chunk (1 = off).
+int dense_fused_iterations(const IterArgs& a) {
+    static const int chunk = [] {
+        const char* e = getenv("PBBI_DENSE_FUSE");
+        const int v = e ? atoi(e) : 32;
+        return v < 1 ? 1 : v;
+    }();
+    if (a.carry != 2 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a) ||
+        a.pot->D != a.pot->DP)  // (the padded-D instantiations of the fused form spill: not built)
+        return 1;
+    return chunk;
+}
+
+// May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Plain
+// Leapfrog on the two-wave kernel at 64 < D <= 128 (the instantiations that exist: each costs ~10 s of
+// build time), both slabs addressable with 32-bit offsets.
+bool dense_carry_applies(const IterArgs& a) {
+    static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
+    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP == 128 && a.N > 0 &&
+           (uint64_t)a.pot->D * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) && getenv("PBBI_DENSE_V1") == nullptr;
 }
 
 int dense_integrate(const IntegrateArgs& a) {

@@ -143,7 +143,8 @@ int route_hmc(const IterArgs& a) {
 // consecutive iterations of pbbi_hmc_run that ONE route_hmc call may cover (IterArgs::fuse_*)
 int route_fused_iterations(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
-    if (pot->kind == KIND_CUSTOM || is_big(pot) || is_dense(pot)) return 1;
+    if (pot->kind == KIND_CUSTOM || is_big(pot)) return 1;
+    if (is_dense(pot)) return dense_fused_iterations(a);
     return lane_fused_iterations(a);
 }
 int route_integrate(const IntegrateArgs& a) {
@@ -736,6 +737,27 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     size_t need = 0;
     void* arena = nullptr;
     int rc = PBBI_OK;
+    // dense MFMA kernel: the gradient at the chain's position is carried from one iteration to the next
+    // (two (D, N) slabs + one byte per chain, kernels_dense.hip CARRY) -- L mat-vecs per iteration, not L + 1
+    char* carry = nullptr;
+    const size_t carry_bytes = 2 * slab * sizeof(double);
+    bool use_carry = false;
+    if (S >= 2 && is_dense(pot) && !is_big(pot) && pot->kind != KIND_CUSTOM) {
+        IterArgs probe{};
+        probe.pot = pot; probe.method = method; probe.N = N; probe.L = L; probe.flags = flags;
+        use_carry = dense_carry_applies(probe);
+    }
+    if (use_carry) {
+        if (hipMallocAsync((void**)&carry, carry_bytes + (size_t)N, st) != hipSuccess) {
+            carry = nullptr;
+            use_carry = false;  // (without the buffers every iteration forms its own gradient)
+            (void)hipGetLastError();
+        } else if (hipMemsetAsync(carry + carry_bytes, 0, (size_t)N, st) != hipSuccess) {
+            (void)hipFreeAsync(carry, st);
+            if (pong) (void)hipFreeAsync(pong, st);
+            return pbbi_fail(PBBI_ERR_HIP, "hipMemsetAsync of the carry selector failed");
+        }
+    }
     for (int i = 0; i < S && rc == PBBI_OK;) {
         IterArgs a{};
         a.pot = pot; a.method = method; a.mass = mass;
@@ -751,6 +773,11 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = st;
         a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
+        if (use_carry) {
+            a.carry = (i == 0) ? 1 : 2;
+            a.carry_g = carry;
+            a.carry_sel = (uint8_t*)(carry + carry_bytes);
+        }
         if (steps_out) {
             if (dyn) a.steps_out = steps_out + (size_t)i * N;
             else hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
@@ -771,6 +798,7 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
         i += chunk > 1 ? chunk : 1;
     }
     if (arena) (void)hipFreeAsync(arena, st);
+    if (carry) (void)hipFreeAsync(carry, st);
     // leave the chain state in q_state (strided D2D copy of the last slab)
     if (rc == PBBI_OK &&
         hipMemcpy2DAsync(q_state, (size_t)ldn * es, slab_of(S - 1), (size_t)N * es, (size_t)N * es,

@@ -112,6 +112,12 @@ struct IterArgs {
     // per-chain trajectory lengths (PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP, pbbi_hmc_*_dyn)
     const int32_t* steps_in;  // uploaded mode; nullptr = L
     int32_t* steps_out;       // optional
+    // gradient carried across the iterations of a run (dense MFMA kernel, kernels_dense.hip CARRY):
+    // carry = 1 first iteration (forms and stores g(q_0)), 2 later ones; carry_g = [2][D][N] doubles,
+    // carry_sel = [N] bytes, zeroed before iteration 0
+    int carry;
+    void* carry_g;
+    uint8_t* carry_sel;
 };
 inline bool pbbi_dyn(const IterArgs& a) { return (a.flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0; }
 
@@ -206,6 +212,8 @@ int stream_eval(const EvalArgs& a);
 int stream_energy(const EvalArgs& a);
 // dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
 int dense_hmc_iter(const IterArgs& a);
+bool dense_carry_applies(const IterArgs& a);  // may a run on these arguments carry the gradient?
+int dense_fused_iterations(const IterArgs& a);  // iterations one launch may cover (carried runs)
 int dense_integrate(const IntegrateArgs& a);
 int dense_eval(const EvalArgs& a);
 int dense_energy(const EvalArgs& a);

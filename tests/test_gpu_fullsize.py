@@ -274,3 +274,45 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
         n_rej += int(rej.sum())
     assert n_rej >= 0.3 * S * N
     assert np.array_equal(to_numpy(qd), samples[S - 1])
+
+
+@pytest.mark.parametrize("D,zero_mean,mass,compat", [(128, True, False, True), (100, False, True, False),
+                                                     (65, True, True, True)])
+def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
+    """pbbi_hmc_run on the dense kernel at 64 < D <= 128 keeps the gradient of the chain's position between
+    iterations (kernels_dense.hip CARRY: accepted chains take g(q_new) of the previous launch, rejected
+    ones the gradient they started from) instead of forming it again.  One run of S iterations must equal
+    S runs of one iteration (which cannot carry anything) bit for bit -- samples, momenta, ratios and
+    decisions -- with a quarter to half of the chains rejecting; a burn-in run (two scratch slabs) ends in the same state."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    N, h, L, S, seed, chain0, iter0 = 1000, 0.7, 4, 7, 3, 19, 2
+    Pm, mu = _stress_problem(D, zero_mean)
+    pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    st = stream_ptr(0)
+    flags = lib.COMPAT_P_FROM_OLDQ if compat else 0
+    q0 = device_normal(lib, seed, lib.STREAM_POSITION, iter0, chain0, D, N, 1.0) + mu[:, None]
+
+    def run(s_per_call):
+        qd = as_device(q0, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None,
+                     samples[i].data_ptr(), momenta[i].data_ptr(), reject[i].data_ptr(), ratio[i].data_ptr(),
+                     N, N, h, L, min(s_per_call, S - i), flags, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one = run(S)        # iterations 1 .. S-1 read the carried gradient
+    each = run(1)       # every iteration forms its own
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.2 < one[2].mean() < 0.8
+    qd = as_device(q0, 0, np.float64)   # burn-in form: nothing recorded, same final state
+    lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, None, None, None,
+             None, N, N, h, L, S, flags, seed, iter0, chain0, 1.0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(qd), one[4])

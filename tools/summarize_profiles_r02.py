@@ -44,15 +44,26 @@ if "FETCH_SIZE" in ev:
     cal["fetch_kb_to_bytes"] = D * N * 8 / ev["FETCH_SIZE"]["mean_per_launch"]
     cal["note"] = ("FETCH_SIZE factor = known bytes read by k_dense_eval (D*N*8) / its FETCH_SIZE: 1024 x the "
                    "gfx950 under-count correction for this 8-B-per-lane access pattern")
+# tools/profile_workload.py runs C2_ITERS iterations of one pbbi_hmc_run: the first on its own launch (forms
+# and stores g(q_0)), the others in one fused launch that carries the gradient -- counters are summed over
+# the launches and divided by the iterations
+C2_ITERS = 9
+tot = lambda c: hm[c]["mean_per_launch"] * hm[c]["launches"]
 if "FETCH_SIZE" in hm and "WRITE_SIZE" in hm:
-    rd = hm["FETCH_SIZE"]["mean_per_launch"] * cal.get("fetch_kb_to_bytes", 2048.0)
-    wr = hm["WRITE_SIZE"]["mean_per_launch"] * 1024.0
-    cal.update(k_dense_hmc_read_bytes_per_launch=rd, k_dense_hmc_write_bytes_per_launch=wr,
-               k_dense_hmc_hbm_bytes_per_launch=rd + wr, algorithmic_bytes_per_launch=(4 * D * 8 + 9) * N)
+    rd = tot("FETCH_SIZE") * cal.get("fetch_kb_to_bytes", 2048.0) / C2_ITERS
+    wr = tot("WRITE_SIZE") * 1024.0 / C2_ITERS
+    cal.update(k_dense_hmc_read_bytes_per_iteration=rd, k_dense_hmc_write_bytes_per_iteration=wr,
+               k_dense_hmc_hbm_bytes_per_iteration=rd + wr, algorithmic_bytes_per_iteration=(4 * D * 8 + 9) * N,
+               executed_bytes_per_iteration=(6 * D * 8 + 9) * N, iterations=C2_ITERS,
+               launches=hm["FETCH_SIZE"]["launches"])
 if "GRBM_GUI_ACTIVE" in hm:
-    cyc = hm["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
-    cal["k_dense_hmc_cycles_per_launch"] = cyc
-    cal["k_dense_hmc_mfma_busy_frac"] = hm["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (1024 * cyc)
+    cyc = tot("GRBM_GUI_ACTIVE") / 8 / C2_ITERS
+    cal["k_dense_hmc_cycles_per_iteration"] = cyc
+    # (SQ_VALU_MFMA_BUSY_CYCLES saturates at 2^32 on the fused launch: busy from the instruction count --
+    #  11 mat-vecs in the first iteration, 10 in each later one, (D/16)(D/4) v_mfma_f64_16x16x4 of 64 cycles
+    #  per mat-vec and 16-chain tile)
+    mfma = (11 + 10 * (C2_ITERS - 1)) * (D // 16) * (D // 4) * (N // 16)
+    cal["k_dense_hmc_mfma_busy_frac"] = mfma * 64 / (1024 * cyc * C2_ITERS)
 out["derived"] = cal
 json.dump(out, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 print("C2", json.dumps(cal, indent=1))
