@@ -67,7 +67,8 @@ struct GemmPrm {
     T* q_next;        // (D, N) drift target (ldw) or nullptr (no drift)
     T* vh;            // (D, N) half-step velocity, updated in place (ldw); EPI_KDK
     const T* minv;    // N: 1/m per chain, or nullptr (= 1)
-    T* grad_out;      // EPI_EVAL: (D, N) with stride ldg, or nullptr
+    T* grad_out;      // (D, N) with stride ldg, or nullptr: the gradient itself (EPI_EVAL's output; EPI_KDK: kept for
+                      // the next iteration of a run, see run_hmc)
     T* xg_part;       // [DPAD/BM][N] partial sums of x*g over the tile's rows, or nullptr
     int64_t N, ldq, ldw, ldg;
     int D, DPAD;
@@ -339,9 +340,8 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
 #ifdef PBBI_BIG_NO_STAGED
         staged = false;
 #endif
-        if constexpr (EPI == EPI_EVAL)
-            staged = staged && (!prm.grad_out || (prm.ldg % 4 == 0 && al16(prm.grad_out)));
-        else
+        staged = staged && (!prm.grad_out || (prm.ldg % 4 == 0 && al16(prm.grad_out)));
+        if constexpr (EPI == EPI_KDK)
             staged = staged && prm.ldw % 4 == 0 && al16(prm.vh) && (!prm.q_next || al16(prm.q_next)) &&
                      (!prm.minv || al16(prm.minv));
         if (staged) {  // block-uniform
@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
                     const f4 v = *reinterpret_cast<const f4*>(prm.vh + o) + (-(g * mi4)) * prm.hk;  // kick
                     *reinterpret_cast<f4*>(prm.vh + o) = v;
                     if (prm.q_next) *reinterpret_cast<f4*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                    if (prm.grad_out) *reinterpret_cast<f4*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;  // carried
                 }
             }
             if (prm.xg_part) {
@@ -393,9 +394,8 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
         constexpr int RGS = NTHR / 64;  // row groups of the read phase (64 column pairs per row)
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         bool staged = (i0 + BM <= prm.D) && (n0 + BN <= prm.N) && q_vec_ok;
-        if constexpr (EPI == EPI_EVAL)
-            staged = staged && (!prm.grad_out || (prm.ldg % 2 == 0 && al16(prm.grad_out)));
-        else
+        staged = staged && (!prm.grad_out || (prm.ldg % 2 == 0 && al16(prm.grad_out)));
+        if constexpr (EPI == EPI_KDK)
             staged = staged && prm.ldw % 2 == 0 && al16(prm.vh) && (!prm.q_next || al16(prm.q_next)) &&
                      (!prm.minv || al16(prm.minv));
         if (staged) {  // block-uniform
@@ -427,6 +427,7 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
                         const d2 v = *reinterpret_cast<const d2*>(prm.vh + o) + (-(g * mi2)) * prm.hk;  // kick
                         *reinterpret_cast<d2*>(prm.vh + o) = v;
                         if (prm.q_next) *reinterpret_cast<d2*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                        if (prm.grad_out) *reinterpret_cast<d2*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;  // carried
                     }
                 }
             }
@@ -466,6 +467,7 @@ __global__ void __launch_bounds__(Cfg<T>::NTHR, Cfg<T>::MIN_WAVES) k_big_gemm(Ge
                 const T v = prm.vh[o] + (-(g * mi)) * prm.hk;  // kick
                 prm.vh[o] = v;
                 if (prm.q_next) prm.q_next[o] = qv + v * prm.h;  // drift into the other buffer
+                if (prm.grad_out) prm.grad_out[(int64_t)i * prm.ldg + n] = g;  // carried to the next iteration
             }
         }
     });
@@ -662,6 +664,7 @@ __global__ void __launch_bounds__(C::NTHR, C::MINW) k_big_gemm_wide(GemmPrm<floa
                     const f4 v = *reinterpret_cast<const f4*>(prm.vh + o) + (-(g * mi4)) * prm.hk;  // kick
                     *reinterpret_cast<f4*>(prm.vh + o) = v;
                     if (prm.q_next) *reinterpret_cast<f4*>(prm.q_next + o) = qv + v * prm.h;  // drift
+                    if (prm.grad_out) *reinterpret_cast<f4*>(prm.grad_out + (int64_t)i * prm.ldg + n) = g;  // carried
                 }
             }
         }
@@ -765,6 +768,43 @@ __global__ void k_big_decide(const T* pp_old_part, const T* pp_new_part, int n_s
     if (ratio_out) ratio_out[n] = ratio;
 }
 
+// Carried gradient (run_hmc): the first half kick and drift of an iteration from the gradient the previous
+// iteration left -- G_new where the chain accepted, G_keep where it did not -- instead of a GEMM:
+//     vh += -(g/m) * hk;  q_next = q + vh * h        (the GEMM epilogue's arithmetic, term for term)
+// and G_keep takes the gradient that is current now.
+template <typename T>
+__global__ void k_big_first_kick(const T* q, int64_t ldq, T* G_keep, const T* G_new, const uint8_t* acc_prev,
+                                 T* vh, const T* minv, T* q_next, int64_t ldw, int D, int64_t N, T hk, T h) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool acc = acc_prev[n] != 0;
+    const T mi = minv ? minv[n] : T(1);
+    const int d0 = blockIdx.y * 16;
+    for (int d = d0; d < d0 + 16 && d < D; ++d) {
+        const int64_t o = (int64_t)d * N + n;
+        const T g = acc ? G_new[o] : G_keep[o];
+        if (acc) G_keep[o] = g;
+        const int64_t w = (int64_t)d * ldw + n;
+        const T v = vh[w] + (-(g * mi)) * hk;
+        vh[w] = v;
+        q_next[w] = q[(int64_t)d * ldq + n] + v * h;
+    }
+}
+
+// after the decision: which gradient / which x.g partial sums are current for the next iteration
+template <typename T>
+__global__ void k_big_carry_update(const uint8_t* reject, uint8_t* acc_prev, const T* xg_old, const T* xg_new,
+                                   T* xg_cur, int n_xg, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const bool rej = reject[n] != 0;
+    acc_prev[n] = rej ? 0 : 1;
+    for (int b = 0; b < n_xg; ++b) {
+        const size_t o = (size_t)b * N + n;
+        xg_cur[o] = rej ? xg_old[o] : xg_new[o];
+    }
+}
+
 // p_new = v_L * m (into pbuf, in place) -- used before the pp_new reduction
 template <typename T>
 __global__ void k_big_v_to_p(T* v, int64_t ld, int D, int64_t N, const T* mass) {
@@ -847,8 +887,8 @@ int gemm(const pbbi_potential* pot, int epi, const T* q, int64_t ldq, T* q_next,
         bool ok = !narrow && pot->zero_mean && pot->D == pot->DPAD_big && pot->D % Wide::BM == 0 && N % Wide::BN == 0 &&
                   ldq % 4 == 0 && al16(q) && al16(prm.PT) &&
                   (int64_t)pot->D * (ldq > pot->D ? ldq : (int64_t)pot->D) * 4 < ((int64_t)1 << 32);
-        if (epi == EPI_EVAL) ok = ok && (!grad_out || (ldg % 4 == 0 && al16(grad_out)));
-        else ok = ok && ldw % 4 == 0 && al16(vh) && (!q_next || al16(q_next)) && (!minv || al16(minv));
+        ok = ok && (!grad_out || (ldg % 4 == 0 && al16(grad_out)));
+        if (epi == EPI_KDK) ok = ok && ldw % 4 == 0 && al16(vh) && (!q_next || al16(q_next)) && (!minv || al16(minv));
         if (ok) {
             const unsigned tiles_w = (unsigned)((pot->D / Wide::BM) * (N / Wide::BN));
             auto gow = [&](auto kernel) -> int {
@@ -931,6 +971,16 @@ int run_hmc(const IterArgs& a) {
     const T* qcur = (const T*)a.q_in;
     int64_t ldcur = a.ldn_in;
     const T* xg_fin = xg_new;
+    // Carried gradient (pbbi_hmc_run, IterArgs::carry): the last GEMM of an iteration is g(q_new) and the
+    // next iteration starts from q_new (accepted) or from where this one started (rejected) -- either way
+    // from a point whose gradient and x.g sums exist.  They are kept (two gradient slabs, one byte and the
+    // partial sums per chain) and the first of the L + 1 GEMMs becomes one elementwise pass.  The decisions
+    // use the very sums the GEMM epilogue would form again, so a run's samples do not change.
+    const int carry = (a.carry && a.carry_g && big_carry_applies(a)) ? a.carry : 0;
+    T* G_keep = carry ? (T*)a.carry_g : nullptr;
+    T* G_new = carry ? G_keep + (size_t)D * N : nullptr;
+    uint8_t* acc_prev = carry ? a.carry_sel : nullptr;
+    T* xg_cur = carry ? (T*)(a.carry_sel + ((size_t)N + 255) / 256 * 256) : nullptr;
     if (!sv && L == 0) {  // nothing moves: one evaluation serves both Hamiltonians
         if (int rc = gemm<T>(pot, EPI_EVAL, qcur, ldcur, nullptr, nullptr, 0, nullptr, nullptr, 0,
                              xg_old, N, T(0), T(0), st))
@@ -943,10 +993,18 @@ int run_hmc(const IterArgs& a) {
         for (int j = 0; j <= L; ++j) {
             const bool first = (j == 0), last = (j == L), drift = sv || !last;
             T* qnext = drift ? ((j & 1) ? qb : qa) : nullptr;
-            if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, nullptr, 0,
-                                 first ? xg_old : ((last && !sv) ? xg_new : nullptr), N,
-                                 (first || (last && !sv)) ? hh : h, h, st))
-                return rc;
+            if (first && carry == 2) {  // the gradient at q_0 exists: no GEMM (xg_old = the carried partial sums)
+                hipLaunchKernelGGL(k_big_first_kick<T>, dim3(g1.x, (unsigned)((D + 15) / 16)), b1, 0, st, qcur,
+                                   ldcur, G_keep, (const T*)G_new, (const uint8_t*)acc_prev, vh, (const T*)minv,
+                                   qnext, (int64_t)N, D, N, hh, h);
+            } else {
+                // a carried run keeps g(q_0) of its first iteration and g(q_L) of every iteration
+                T* gkeep = (carry && first) ? G_keep : ((carry && last) ? G_new : nullptr);
+                if (int rc = gemm<T>(pot, EPI_KDK, qcur, ldcur, qnext, vh, N, minv, gkeep, N,
+                                     first ? xg_old : ((last && !sv) ? xg_new : nullptr), N,
+                                     (first || (last && !sv)) ? hh : h, h, st))
+                    return rc;
+            }
             if (drift) { qcur = qnext; ldcur = N; }
         }
         if (sv)
@@ -957,10 +1015,14 @@ int run_hmc(const IterArgs& a) {
     hipLaunchKernelGGL(k_big_v_to_p<T>, grid2d(N, D), b1, 0, st, vh, (int64_t)N, D, N, (const T*)a.mass);
     hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)vh,
                        (int64_t)N, D, N, SQ_ROWS, pp_new);
+    const T* xg_start = (carry == 2) ? (const T*)xg_cur : (const T*)xg_old;
     hipLaunchKernelGGL(k_big_decide<T>, g1, b1, 0, st, (const T*)pp_old, (const T*)pp_new, n_sq,
-                       (const T*)xg_old, xg_fin, n_xg, (const T*)a.mass, (const T*)a.u_in,
+                       xg_start, xg_fin, n_xg, (const T*)a.mass, (const T*)a.u_in,
                        a.rng, a.seed, a.iter, a.chain0, (T)pot->cst, (T)pbbi_accept_beta(a.flags, a.kT), N,
                        (T*)a.ratio_out, rej);
+    if (carry)
+        hipLaunchKernelGGL(k_big_carry_update<T>, g1, b1, 0, st, (const uint8_t*)rej, acc_prev, xg_start, xg_fin,
+                           xg_cur, n_xg, N);
     hipLaunchKernelGGL(k_big_select<T>, grid2d(N, D), b1, 0, st, (const T*)a.q_in, a.ldn_in, qcur,
                        (const T*)vh, (const T*)pdraw, (int64_t)N, (const uint8_t*)rej,
                        (a.flags & PBBI_COMPAT_P_FROM_OLDQ) ? 1 : 0, (T*)a.q_out, (T*)a.p_out,
@@ -1070,6 +1132,18 @@ int big_build(pbbi_potential* pot, const double* P, const double* mean) {
     PBBI_HIP(hipMemcpy(pot->d_big_PT, buf.data(), buf.size(), hipMemcpyHostToDevice));
     PBBI_HIP(hipMemcpy(pot->d_big_mu, mub.data(), mub.size(), hipMemcpyHostToDevice));
     return PBBI_OK;
+}
+
+// May the iterations of a run on these arguments carry the gradient (run_hmc)?  Plain Leapfrog, L >= 1.
+bool big_carry_applies(const IterArgs& a) {
+    static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
+    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->d_big_PT != nullptr && a.N > 0;
+}
+// bytes of IterArgs::carry_g (two gradient slabs) and of IterArgs::carry_sel (accept bytes + x.g partial sums)
+void big_carry_bytes(const pbbi_potential* pot, int64_t N, size_t* g_bytes, size_t* sel_bytes) {
+    const size_t es = pot->dtype == PBBI_F64 ? 8 : 4;
+    *g_bytes = 2 * (size_t)pot->D * (size_t)N * es;
+    *sel_bytes = ((size_t)N + 255) / 256 * 256 + (size_t)(pot->DPAD_big / BM) * (size_t)N * es;
 }
 
 int big_hmc_iter(const IterArgs& a) {

@@ -562,7 +562,10 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         __syncthreads();
     }
     // Static priority for one of the two waves that share a SIMD (waves w and w+4).
-    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#ifndef PBBI_DENSE_FUSE_PRIO
+#define PBBI_DENSE_FUSE_PRIO 1
+#endif
+    if ((!FUSE || PBBI_DENSE_FUSE_PRIO) && wave < 4) __builtin_amdgcn_s_setprio(1);
     STAMP(1);
     const int g = lane >> 4;
     const int c = lane & 15;
@@ -1119,7 +1122,7 @@ int dense_hmc_iter(const IterArgs& a) {
 int dense_fused_iterations(const IterArgs& a) {
     static const int chunk = [] {
         const char* e = getenv("PBBI_DENSE_FUSE");
-        const int v = e ? atoi(e) : 32;
+        const int v = e ? atoi(e) : 64;
         return v < 1 ? 1 : v;
     }();
     if (a.carry != 2 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a) ||

@@ -740,19 +740,24 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     // dense MFMA kernel: the gradient at the chain's position is carried from one iteration to the next
     // (two (D, N) slabs + one byte per chain, kernels_dense.hip CARRY) -- L mat-vecs per iteration, not L + 1
     char* carry = nullptr;
-    const size_t carry_bytes = 2 * slab * sizeof(double);
+    size_t carry_bytes = 2 * slab * sizeof(double), sel_bytes = (size_t)N;
     bool use_carry = false;
-    if (S >= 2 && is_dense(pot) && !is_big(pot) && pot->kind != KIND_CUSTOM) {
+    if (S >= 2 && pot->kind != KIND_CUSTOM && (is_dense(pot) || is_big(pot))) {
         IterArgs probe{};
         probe.pot = pot; probe.method = method; probe.N = N; probe.L = L; probe.flags = flags;
-        use_carry = dense_carry_applies(probe);
+        if (is_big(pot)) {  // the GEMM path keeps the x.g partial sums next to the accept bytes
+            use_carry = big_carry_applies(probe);
+            big_carry_bytes(pot, N, &carry_bytes, &sel_bytes);
+        } else {
+            use_carry = dense_carry_applies(probe);
+        }
     }
     if (use_carry) {
-        if (hipMallocAsync((void**)&carry, carry_bytes + (size_t)N, st) != hipSuccess) {
+        if (hipMallocAsync((void**)&carry, carry_bytes + sel_bytes, st) != hipSuccess) {
             carry = nullptr;
             use_carry = false;  // (without the buffers every iteration forms its own gradient)
             (void)hipGetLastError();
-        } else if (hipMemsetAsync(carry + carry_bytes, 0, (size_t)N, st) != hipSuccess) {
+        } else if (hipMemsetAsync(carry + carry_bytes, 0, sel_bytes, st) != hipSuccess) {
             (void)hipFreeAsync(carry, st);
             if (pong) (void)hipFreeAsync(pong, st);
             return pbbi_fail(PBBI_ERR_HIP, "hipMemsetAsync of the carry selector failed");

@@ -213,7 +213,9 @@ int stream_energy(const EvalArgs& a);
 // dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
 int dense_hmc_iter(const IterArgs& a);
 bool dense_carry_applies(const IterArgs& a);  // may a run on these arguments carry the gradient?
-int dense_fused_iterations(const IterArgs& a);  // iterations one launch may cover (carried runs)
+int dense_fused_iterations(const IterArgs& a);
+bool big_carry_applies(const IterArgs& a);     // the same for the GEMM path (kernels_big.hip)
+void big_carry_bytes(const pbbi_potential* pot, int64_t N, size_t* g_bytes, size_t* sel_bytes);  // iterations one launch may cover (carried runs)
 int dense_integrate(const IntegrateArgs& a);
 int dense_eval(const EvalArgs& a);
 int dense_energy(const EvalArgs& a);

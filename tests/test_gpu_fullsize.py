@@ -316,3 +316,43 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
              None, N, N, h, L, S, flags, seed, iter0, chain0, 1.0, st)
     torch.cuda.synchronize()
     assert np.array_equal(to_numpy(qd), one[4])
+
+
+@pytest.mark.parametrize("D,N,dtype,zero_mean,mass", [(512, 768, "float32", True, False),
+                                                      (200, 150, "float64", False, True),
+                                                      (384, 300, "float32", False, True)])
+def test_gemm_path_run_carries_the_gradient_bit_identically(P, lib, D, N, dtype, zero_mean, mass):
+    """The same on the GEMM path (kernels_big.hip, D > 128 / fp32): inside pbbi_hmc_run the first of the
+    L + 1 GEMMs of an iteration is replaced by one elementwise pass over the gradient the previous iteration
+    kept (its last GEMM's for accepted chains, the older one for rejected chains), and H_old by the kept x.g
+    partial sums.  One run of S iterations == S runs of one, bit for bit, rejections included."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    h, L, S, seed, chain0, iter0 = 0.35, 3, 5, 4, 9, 1
+    npdt = np.float32 if dtype == "float32" else np.float64
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    mu = None if zero_mean else rs.standard_normal(D) * 0.5
+    pot = P.GaussianDense(mu, precision=Pm, const=0.1, dtype=dtype)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, npdt) if mass else None
+    st = stream_ptr(0)
+    q0 = rs.standard_normal((D, N))
+
+    def run(s_per_call):
+        qd = as_device(q0, 0, npdt)
+        samples, momenta = empty((S, D, N), npdt, 0), empty((S, D, N), npdt, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), npdt, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None,
+                     samples[i].data_ptr(), momenta[i].data_ptr(), reject[i].data_ptr(), ratio[i].data_ptr(),
+                     N, N, h, L, min(s_per_call, S - i), lib.COMPAT_P_FROM_OLDQ, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one, each = run(S), run(1)
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.05 < one[2].mean() < 0.95
