@@ -416,7 +416,9 @@ def bench_c2(args, rank, world, local_rank):
     # the point it started at) and covers up to PBBI_DENSE_FUSE (64) iterations per launch: L mat-vecs per
     # iteration are EXECUTED where SURVEY 8d's algorithmic figure counts L + 1.  Both rates are reported.
     carried = os.environ.get("PBBI_NO_CARRY") is None
-    fuse = max(1, int(os.environ.get("PBBI_DENSE_FUSE", "64"))) if carried else 1
+    fuse_max = max(1, int(os.environ.get("PBBI_DENSE_FUSE", "64"))) if carried else 1
+    # a timed run = one pbbi_hmc_run of K iterations: the first on its own launch, the rest in equal fused launches
+    fuse = (K - 1) / (-(-(K - 1) // fuse_max)) if (fuse_max > 1 and K > 1) else 1
     flops_exec = (2.0 * D * D * (L if carried else L + 1) + 11.0 * D * L + 8.0 * D) * N
     bytes_exec = bytes_launch + (2.0 * D * 8 * N if carried else 0.0)  # g read + g(q_new) written
     out = {

@@ -790,6 +790,10 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
         }
         // kernels that keep the chain on chip take several iterations per launch
         int chunk = route_fused_iterations(a);
+        if (chunk > 1) {  // launches of (nearly) equal length instead of full chunks and a short tail
+            const int rem = S - i, launches = (rem + chunk - 1) / chunk;
+            chunk = (rem + launches - 1) / launches;
+        }
         if (chunk > S - i) chunk = S - i;
         if (chunk > 1) {
             a.fuse_S = chunk;
