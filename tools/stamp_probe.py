@@ -27,7 +27,7 @@ stamps = torch.zeros((nblk * 8, 64), dtype=torch.int64, device="cuda")
 lib.pbbi_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.pbbi_debug_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 q = torch.randn((D, N), dtype=torch.float64, device="cuda")
-S = 3
+S = int(os.environ.get("STAMP_ITERS", "3"))
 samples = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 mom = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 rej = torch.empty((S, N), dtype=torch.uint8, device="cuda")
