@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define PBBI_VERSION 101 /* major*100 + minor */
+#define PBBI_VERSION 102 /* major*100 + minor */
 
 enum { PBBI_OK = 0, PBBI_ERR_INVALID = -1, PBBI_ERR_UNSUPPORTED = -2, PBBI_ERR_HIP = -3 };
 enum { PBBI_F64 = 0, PBBI_F32 = 1 };
@@ -216,6 +216,10 @@ int pbbi_hmc_iter_kt(const pbbi_potential* pot, int method, const void* q_in, co
  * iter0 + S must not exceed 2^32: the Philox counter carries 32 iteration bits, a larger index
  * would repeat the draws of iteration (index mod 2^32) and is refused (PBBI_ERR_INVALID).  Runs
  * that must not share draws (a warm-up and the sampling that follows) use different seeds.
+ * The run is the unit of work: consecutive iterations may share one launch, and the dense-Gaussian paths
+ * keep the gradient of the chain's current position between iterations (the loop of src/HMC.py:150-179
+ * evaluates it again at the top of every iteration, src/integrator.py:105-108).  Neither changes a
+ * result: a run of S iterations equals S runs of one iteration bit for bit.
  */
 int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const void* mass,
                  void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,

@@ -62,7 +62,7 @@ def _dist():
     return dist
 
 
-def gather_samples(local_sdn, group=None):
+def gather_samples(local_sdn, group=None, _force_collective=False):
     """All-gather per-rank (S, D, N_local) slabs along the chain axis -> (S, D, N_total) on
     every rank (rank r's chains at columns shard_bounds(N_total, r, world)).  One collective:
     `all_gather_into_tensor` when the shards are equal, a padded one otherwise.  Works on CUDA
@@ -72,7 +72,7 @@ def gather_samples(local_sdn, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local_sdn
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _force_collective:  # (_force_collective: the one-rank RCCL test on a one-GPU box)
         return local_sdn
     S, D, Nl = local_sdn.shape
     sizes = torch.tensor([Nl], dtype=torch.int64, device=local_sdn.device)

@@ -11,6 +11,7 @@ Tolerances (fp64):
   reject masks: EQUAL in every case (the fixtures hold no |u - ratio| tie).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1979,3 +1980,47 @@ def test_rosenbrock_multilane_reference_order_bitexact(P, lib, D, N, mass, compa
             _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L, compat=flags)
             assert np.array_equal(to_numpy(reject[i]).astype(bool), rej)
             assert np.array_equal(to_numpy(samples[i]), q) and np.array_equal(to_numpy(momenta[i]), p)
+
+
+def test_rccl_collectives_run_on_hardware_single_rank():
+    """The collectives of the sharded path on RCCL itself.  This pool hands out one GPU, so the
+    world is one rank: `init_process_group("nccl")` on cuda:0, then the all-gather of sample slabs
+    (`distributed.gather_samples`) and the two all-reduces of `distributed.ensemble_weights` on HIP tensors,
+    in a child process (the process group must not leak into this one).  World size > 1 is covered on
+    gloo (tests/test_host_logic.py) and by the driver's multi-GPU bench."""
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from physicsbasedbayesianinference_amd import distributed as D
+        torch.cuda.set_device(0)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        except Exception as e:
+            print("RCCL-INIT-FAILED", repr(e)); sys.exit(0)
+        x = torch.arange(2 * 3 * 5, dtype=torch.float64, device="cuda").reshape(2, 3, 5)
+        y = D.gather_samples(x, _force_collective=True)
+        assert y.shape == x.shape and torch.equal(y, x)
+        H = torch.tensor([0.5, 1.5, 0.25, 3.0], dtype=torch.float64, device="cuda")
+        t = H.min().clone(); dist.all_reduce(t, op=dist.ReduceOp.MIN); assert float(t) == 0.25
+        s = H.sum().clone(); dist.all_reduce(s, op=dist.ReduceOp.SUM); assert float(s) == 5.25
+        w, logz = D.ensemble_weights(H, beta=2.0)
+        ref = np.exp(-2.0 * (H.cpu().numpy() - 0.25)); ref /= ref.sum()
+        assert np.allclose(w.cpu().numpy(), ref, rtol=1e-13)
+        dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
+        print("RCCL-OK", dist.is_nccl_available())
+    """ % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    if "RCCL-INIT-FAILED" in out:
+        pytest.skip("RCCL could not initialise on this box: " + out[-300:])
+    assert r.returncode == 0 and "RCCL-OK" in out, out[-2000:]

@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol():
     assert sorted(_lib.PROTOTYPES) == declared, "ctypes table and header drifted apart"
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pbbi_version() == 101
+    assert lib.pbbi_version() == 102
     # the symbols are really exported by the shared object (not resolved from elsewhere)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
                          text=True).stdout
