@@ -231,8 +231,9 @@ __device__ __forceinline__ double pp_pair(const double (&p)[DL]) {
 // leapfrog_chain_dyn), so they stay paired for the q_16 / carry exchanges inside the masked loop.
 template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
 __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& pot, int64_t n0, int c,
-                                          int half, bool valid, int cc, double (&q)[DL],
-                                          const int32_t* steps_in = nullptr, int32_t* steps_out = nullptr) {
+                                          int half, bool valid, int cc, double (&q)[DL], double& U_carry,
+                                          bool have_U, const int32_t* steps_in = nullptr,
+                                          int32_t* steps_out = nullptr) {
     static_assert(!(KDK && DYN), "per-chain lengths run in the reference-order form");
     const int D = prm.D;
     const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
@@ -267,12 +268,16 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     };
     if (prm.rng) draw(); else load_p();
 
-    // H(q_old, p_old), src/HMC.py:109-111; correct in the half-1 lanes, then shared with half 0
+    // H(q_old, p_old), src/HMC.py:109-111; correct in the half-1 lanes, then shared with half 0.
+    // U(q_old): inside a fused run the position is the one the previous iteration ended on, whose
+    // potential energy that iteration already formed (U of its proposal if it accepted, its own U(q_old)
+    // if it rejected): the same value, carried in a register instead of evaluated again.
+    const double U_old = have_U ? U_carry : (KDK ? pot.U_pair(q) : pot.U(q));
     double oldH;
     if constexpr (KDK) {
-        oldH = 0.5 * pp_pair(v) / m + pot.U_pair(q);
+        oldH = 0.5 * pp_pair(v) / m + U_old;
     } else {
-        oldH = 0.5 * pp_seq(v, half) / m + pot.U(q);
+        oldH = 0.5 * pp_seq(v, half) / m + U_old;
         const double o = xchg(oldH);
         if (!half) oldH = o;
     }
@@ -350,11 +355,12 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
         for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
     }
 
+    const double U_new = KDK ? pot.U_pair(q) : pot.U(q);
     double newH;
     if constexpr (KDK) {
-        newH = 0.5 * pp_pair(v) / m + pot.U_pair(q);
+        newH = 0.5 * pp_pair(v) / m + U_new;
     } else {
-        newH = 0.5 * pp_seq(v, half) / m + pot.U(q);
+        newH = 0.5 * pp_seq(v, half) / m + U_new;
         const double o = xchg(newH);
         if (!half) newH = o;
     }
@@ -362,6 +368,7 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    U_carry = reject ? U_old : U_new;  // U of the position the chain holds now (both lanes of a chain decide alike)
     if (reject) {
 #pragma unroll
         for (int j = 0; j < DL; ++j)
@@ -447,6 +454,7 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
     double q[DL];
 #pragma unroll
     for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
+    double U_carry = 0.0;  // U at the position in q[], from the second iteration of the launch on
 #pragma nounroll
     for (int k = 0; k < run.S; ++k) {
         Ros2Prm it = prm;  // this iteration's view: where a rejected chain re-reads its position, where the results go
@@ -461,8 +469,11 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
         if (prm.ratio_out) it.ratio_out = prm.ratio_out + (int64_t)k * prm.N;
         if (prm.reject_out) it.reject_out = prm.reject_out + (int64_t)k * prm.N;
         it.iter = prm.iter + (uint64_t)k;
-        if constexpr (DYN) ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, run.steps_in, run.steps_out);
-        else ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q);
+        if constexpr (DYN) {  // (at the register limit: it evaluates U(q_old) every iteration rather than spill)
+            double unused = 0.0;
+            ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, unused, false, run.steps_in, run.steps_out);
+        }
+        else ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q, U_carry, k > 0);
     }
 #ifdef PBBI_STAMPS_ROS2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
