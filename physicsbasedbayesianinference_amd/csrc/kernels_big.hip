@@ -26,6 +26,10 @@
 //
 // Stormer-Verlet runs on the same epilogue: no closing half kick, one more drift, and one
 // evaluation GEMM for U of the final position.
+//
+// Inside pbbi_hmc_run the gradient of the point an iteration starts from is carried over from the
+// previous iteration (run_hmc): L GEMMs per Leapfrog iteration, the first half kick is an elementwise pass.
+// fp32, zero mean, whole aligned tiles (config C5's every block) run on k_big_gemm_wide (256 x 128 tiles).
 #include <cstdlib>
 #include <vector>
 
