@@ -232,8 +232,8 @@ __device__ __forceinline__ double pp_pair(const double (&p)[DL]) {
 template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
 __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& pot, int64_t n0, int c,
                                           int half, bool valid, int cc, double (&q)[DL], double& U_carry,
-                                          bool have_U, const int32_t* steps_in = nullptr,
-                                          int32_t* steps_out = nullptr) {
+                                          bool have_U, double (&a)[DL], bool& a_valid,
+                                          const int32_t* steps_in = nullptr, int32_t* steps_out = nullptr) {
     static_assert(!(KDK && DYN), "per-chain lengths run in the reference-order form");
     const int D = prm.D;
     const double m = UNIT ? 1.0 : prm.mass[n0 + cc];
@@ -250,7 +250,7 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return pot.exists(j); };
 
-    double v[DL], a[DL];  // v holds p, then the velocity, then p again
+    double v[DL];  // v holds p, then the velocity, then p again (a: the caller's, see a_valid below)
     [[maybe_unused]] int steps = 0;  // DYN: leapfrog steps this chain took
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
     auto draw = [&]() {
@@ -339,7 +339,10 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
             }
         }
     } else {
-        pot.neg_grad_each(q, [&](int j, double ng) { a[j] = UNIT ? ng : ng / m; });
+        // a = -grad U(q)/m at the starting point.  In a fused run it is what the previous iteration's last
+        // step left in a[] -- unless a chain of this wave rejected and went back: then (a_valid false) the
+        // wave evaluates it again, which gives the accepted chains the values they already hold.
+        if (!a_valid) pot.neg_grad_each(q, [&](int j, double ng) { a[j] = UNIT ? ng : ng / m; });
         for (int s = 0; s < prm.L; ++s) {
 #pragma unroll
             for (int j = 0; j < DL; ++j) q[j] += (v[j] * h + a[j] * hh2);
@@ -369,6 +372,7 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     U_carry = reject ? U_old : U_new;  // U of the position the chain holds now (both lanes of a chain decide alike)
+    if constexpr (!KDK && !DYN) a_valid = (__builtin_amdgcn_ballot_w64(reject) == 0);
     if (reject) {
 #pragma unroll
         for (int j = 0; j < DL; ++j)
@@ -455,6 +459,8 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
 #pragma unroll
     for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
     double U_carry = 0.0;  // U at the position in q[], from the second iteration of the launch on
+    [[maybe_unused]] double a_carry[DL];  // reference-order form: -grad U / m there, while a_valid
+    bool a_valid = false;
 #pragma nounroll
     for (int k = 0; k < run.S; ++k) {
         Ros2Prm it = prm;  // this iteration's view: where a rejected chain re-reads its position, where the results go
@@ -469,11 +475,14 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
         if (prm.ratio_out) it.ratio_out = prm.ratio_out + (int64_t)k * prm.N;
         if (prm.reject_out) it.reject_out = prm.reject_out + (int64_t)k * prm.N;
         it.iter = prm.iter + (uint64_t)k;
-        if constexpr (DYN) {  // (at the register limit: it evaluates U(q_old) every iteration rather than spill)
-            double unused = 0.0;
-            ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, unused, false, run.steps_in, run.steps_out);
+        if constexpr (DYN) {  // (at the register limit: it evaluates U(q_old) and a(q_old) every iteration rather than spill)
+            double unused = 0.0, a_dyn[DL];
+            bool no = false;
+            ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, unused, false, a_dyn, no, run.steps_in,
+                                             run.steps_out);
+        } else {
+            ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q, U_carry, k > 0, a_carry, a_valid);
         }
-        else ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q, U_carry, k > 0);
     }
 #ifdef PBBI_STAMPS_ROS2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
