@@ -631,6 +631,30 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     // ---- momentum: one Philox block per 4 rows (RNG mode) or the uploaded p_in, then q
     double vh[KS];
     v4f64 acc[NTP];
+    // rows of pass PASS of the carried gradient <-> acc (element s = 4*(PASS*NTP + t) + r, like q[s])
+    auto carry_load = [&](auto pass_c) {
+        constexpr int PASS = decltype(pass_c)::value;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[t][r] = load_elem<FULL>(gbuf, vg_cur, s4g, ld_g, 4 * (PASS * NTP + t) + r, g, D);
+    };
+    auto carry_store = [&](auto pass_c, uint32_t voff) {
+        constexpr int PASS = decltype(pass_c)::value;
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_elem<FULL>(gbuf, voff, s4g, 4 * (PASS * NTP + t) + r, g, D, acc[t][r]);
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // fused run: the first pass of the carried gradient is requested before the draw (acc is idle until
+    // the draw is done, and a thousand vector instructions cover the round trip)
+    if constexpr (CARRY == 2 && FUSE) carry_load(P0{});
     if (rng) {
         const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
         const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
@@ -670,29 +694,11 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
 
     // ---- g(q_0) in row passes: U(q_old) and the first half kick
     const double ck = h * minv, ckh = 0.5 * ck;  // kick coefficients h/m and h/(2m)
-    // rows of pass PASS of the carried gradient <-> acc (element s = 4*(PASS*NTP + t) + r, like q[s])
-    auto carry_load = [&](auto pass_c) {
-        constexpr int PASS = decltype(pass_c)::value;
-#pragma unroll
-        for (int t = 0; t < NTP; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[t][r] = load_elem<FULL>(gbuf, vg_cur, s4g, ld_g, 4 * (PASS * NTP + t) + r, g, D);
-    };
-    auto carry_store = [&](auto pass_c, uint32_t voff) {
-        constexpr int PASS = decltype(pass_c)::value;
-        if (valid) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    store_elem<FULL>(gbuf, voff, s4g, 4 * (PASS * NTP + t) + r, g, D, acc[t][r]);
-        }
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    if constexpr (CARRY == 2) carry_load(P0{});
-    else matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+    if constexpr (CARRY == 2) {
+        if constexpr (!FUSE) carry_load(P0{});
+    } else {
+        matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+    }
     if constexpr (CARRY == 1) carry_store(P0{}, vg_cur);
     double xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
     kick_pass<NT, NTP, 0>(vh, acc, ckh);
