@@ -231,8 +231,10 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
  * [0, L]; NULL = L for every chain.  steps_out (N, or (S, N) for run; may be NULL): the steps each
  * chain took.  Leapfrog only.  Served by the chain-per-lane kernels (harmonic, diagonal Gaussian,
  * Rosenbrock: fp64, D <= 32, reference operation order whatever PBBI_KDK_FMA says, bit-exact with the
- * oracle) and, for PBBI_PER_CHAIN_STEPS, by the dense MFMA kernel (D <= 128); other paths return
- * PBBI_ERR_UNSUPPORTED. */
+ * oracle) and by the dense MFMA kernel (D <= 128, both flags: the 16-chain tile keeps stepping while
+ * one of its chains is live; the U-turn quantity is formed from the kernel's kick-drift-kick values, so a
+ * chain whose (q - q_0) . v passes zero within rounding may stop one step apart from a reference-order
+ * run); other paths return PBBI_ERR_UNSUPPORTED. */
 int pbbi_hmc_iter_dyn(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
                       const void* u_in, const void* mass, const int32_t* steps_in, void* q_out, void* p_out,
                       void* ratio_out, uint8_t* reject_out, int32_t* steps_out, int64_t N, int64_t ldn,

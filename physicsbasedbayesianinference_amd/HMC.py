@@ -516,7 +516,8 @@ class HMC:
         step counts over the second half of the warm-up becomes numSteps (simulTime = numSteps*stepSize).
         Stopping at a U-turn is not a reversible move, so these iterations only MEASURE: the recorded run
         afterwards uses the fixed (or jittered / per-chain random) length, which is.  Elementwise
-        potentials with D <= 32 (include/pbbi.h); the warm-up state is discarded.  Returns simulTime."""
+        potentials with D <= 32 and dense Gaussians with D <= 128 (include/pbbi.h); the warm-up state is
+        discarded.  Returns simulTime."""
         pot, ens = self._pot, self.ensemble
         D, N = ens.numDimensions, ens.numParticles
         if N == 0:

@@ -713,29 +713,78 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
     STAMP(4);
     xg = 0.0;
-    int Ln = prm.L, Lw = prm.L;  // this chain's steps, the wave's
+    int Ln = prm.L;  // this chain's steps
     if constexpr (DYN) {
-        if (rng) Ln = rng_steps(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc), prm.L);
+        // Per-chain lengths.  Chain c takes Ln <= L steps (drawn or uploaded) and, with PBBI_UTURN_STOP, stops
+        // at the first step j where (q_j - q_0) . v_j < 0.  The 16-chain tile keeps stepping while any of its
+        // chains is live; a chain that has finished is frozen by per-lane coefficients (drift step 0, kick 0),
+        // never by a branch around the register arrays, and every executed step recomputes g at its (fixed)
+        // position, so x.g of the last executed step is x.g at every chain's final position.
+        //   * a chain whose last step is known in advance (Ln) gets its closing HALF kick there;
+        //   * a U-turn is known only after the step's full kick: the chain then owes half a kick BACK,
+        //     -(h/2m)(-g_j), paid at the next executed step (where g_j is formed again) -- if necessary an
+        //     extra step that moves nothing.  v_j for the test is vh_{j-1/2} - (h/2m) g_j, formed pass by pass
+        //     before the kick; q_0 is re-read from the iteration's input (the start point does not fit the
+        //     registers).
+        if (rng) Ln = (prm.flags & PBBI_PER_CHAIN_STEPS)
+                          ? rng_steps(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc), prm.L) : prm.L;
         else if (prm.steps_in) Ln = prm.steps_in[n0 + cc];
         Ln = Ln < 1 ? 1 : (Ln > prm.L ? prm.L : Ln);
-        Lw = Ln;
+        const bool uturn = (prm.flags & PBBI_UTURN_STOP) != 0;
+        bool alive = true;
+        double pend = 0.0;  // kick coefficient owed (0 or -h/2m)
+        int taken = Ln;
+        auto uturn_dot = [&](auto pass_c) {  // sum over this pass's rows of (q - q_0) * v_j
+            constexpr int PASS = decltype(pass_c)::value;
+            double q0r[4 * NTP];
 #pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) {  // the 16 chains of the wave (lanes that differ in bits 0-3)
-            const int o = __shfl_xor(Lw, sft, 64);
-            Lw = o > Lw ? o : Lw;
+            for (int t = 0; t < 4 * NTP; ++t) q0r[t] = load_elem<FULL>(qin_k, vin, s4in, ld_in, 4 * PASS * NTP + t, g, D);
+            double sum = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * (PASS * NTP + t) + r;
+                    sum = fma(q[s] - q0r[4 * t + r], fma(-acc[t][r], ckh, vh[s]), sum);
+                }
+            return sum;
+        };
+        using U0 = std::integral_constant<int, 0>;
+        using U1 = std::integral_constant<int, 1>;
+        for (int j = 0; j <= prm.L; ++j) {  // at most L steps and one step that only pays a kick back
+            const bool active = alive && j < Ln;
+            if (__builtin_amdgcn_ballot_w64(active || pend != 0.0) == 0) break;  // wave-uniform
+            const double cj = active ? (j == Ln - 1 ? ckh : ck) : pend;
+            const double hq = active ? h : 0.0;
+            pend = 0.0;
+            double dot = 0.0;
+            matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, hq);  // drift + g(q_{j+1})
+            if (MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+            if (uturn) dot = uturn_dot(U0{});
+            kick_pass<NT, NTP, 0>(vh, acc, cj);
+            if constexpr (NPASS == 2) {
+                matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
+                if (MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+                if (uturn) dot += uturn_dot(U1{});
+                kick_pass<NT, NTP, 1>(vh, acc, cj);
+            }
+            if (uturn) {
+                dot = chain_sum(dot);
+                if (active && j != Ln - 1 && dot < 0.0) {  // (at its known last step the chain ends anyway)
+                    alive = false;
+                    taken = j + 1;
+                    pend = -ckh;
+                }
+            }
+            if (active && j == Ln - 1) alive = false;
         }
-        Lw = __builtin_amdgcn_readfirstlane(Lw);
-    }
-    for (int j = 0; j < Lw; ++j) {
-        const bool last = (j == Lw - 1) && METHOD == PBBI_LEAPFROG;
-        double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
-        double hq = h;
-        if constexpr (DYN) {
-            cj = j < Ln ? (j == Ln - 1 ? ckh : ck) : 0.0;
-            hq = j < Ln ? h : 0.0;
-        }
+        Ln = taken;
+    } else {
+    for (int j = 0; j < prm.L; ++j) {
+        const bool last = (j == prm.L - 1) && METHOD == PBBI_LEAPFROG;
+        const double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
         STAMP(5 + 2 * j);
-        matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, hq);  // drift + g(q_{j+1})
+        matvec_pass<NT, NTP, 0, true, ZMEAN>(fragL, muG, q, vh, acc, h);  // drift + g(q_{j+1})
         if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
         if constexpr (CARRY != 0)
             if (last) carry_store(P0{}, vg_new);  // g(q_new), for the next iteration if this one accepts
@@ -748,6 +797,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
                 if (last) carry_store(P1{}, vg_new);
             kick_pass<NT, NTP, 1>(vh, acc, cj);
         }
+    }
     }
     if constexpr (METHOD == PBBI_STORMER_VERLET) {
         // position step L+1 (:155-159 on the last pass of the reference's loop)
@@ -949,7 +999,7 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const int64_t tiles2 = (N + CHAINS_PER_WG2 - 1) / CHAINS_PER_WG2;
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
         const bool zmean = pot->zero_mean;
-        const bool dyn = prm.mode == 0 && (prm.flags & PBBI_PER_CHAIN_STEPS) != 0;
+        const bool dyn = prm.mode == 0 && (prm.flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0;
         const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
@@ -1077,11 +1127,8 @@ int dense_build_fragments(pbbi_potential* pot, const double* P, const double* me
 
 int dense_hmc_iter(const IterArgs& a) {
     if (int rc = check(a.pot)) return rc;
-    if (a.flags & PBBI_UTURN_STOP)
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "PBBI_UTURN_STOP is not served by the dense MFMA kernel (the start "
-                                               "point does not fit its registers); PBBI_PER_CHAIN_STEPS is");
-    if ((a.flags & PBBI_PER_CHAIN_STEPS) && (a.method != PBBI_LEAPFROG || a.L < 1))
-        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "PBBI_PER_CHAIN_STEPS on the dense kernel: Leapfrog with L >= 1");
+    if (pbbi_dyn(a) && (a.method != PBBI_LEAPFROG || a.L < 1))
+        return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths on the dense kernel: Leapfrog with L >= 1");
     if (int rc = check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
     if (a.N == 0) return PBBI_OK;
     DensePrm prm{};

@@ -1810,7 +1810,7 @@ def test_per_chain_steps_lane_kernels_bitexact(P, lib, case, mass, mode):
 @pytest.mark.parametrize("rng", ["upload", "philox"])
 def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
     """PBBI_PER_CHAIN_STEPS on the dense MFMA kernel (finished chains frozen by per-lane coefficients, the
-    tile runs its longest chain): counts, decisions and states against the oracle; U-turn stop refused."""
+    tile runs its longest chain): counts, decisions and states against the oracle."""
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     rs = np.random.RandomState(5)
@@ -1847,9 +1847,48 @@ def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
     assert np.array_equal(to_numpy(so), st_or) and len(np.unique(st_or)) == L
     assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
     assert scaled_err(to_numpy(qo), q_or) <= RTOL_DENSE and scaled_err(to_numpy(po), p_or) <= RTOL_DENSE
-    with pytest.raises(lib.PbbiError):
-        lib.call("pbbi_hmc_run_dyn", pot.handle, 0, qd.data_ptr(), None, qo.data_ptr(), po.data_ptr(), rj.data_ptr(),
-                 ro.data_ptr(), so.data_ptr(), N, N, h, L, 1, flags | lib.UTURN_STOP, seed, 0, 0, 1.0, stream_ptr(0))
+
+
+@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True)])
+@pytest.mark.parametrize("mode", ["uturn", "both"])
+def test_uturn_stop_dense_kernel(P, lib, case, mass, mode):
+    """PBBI_UTURN_STOP on the dense MFMA kernel: a chain stops at the first step where (q - q_0) . v < 0 (the
+    tile keeps stepping for its other chains; the chain's last full kick is brought back to a half kick at the
+    next executed step).  Step counts, decisions and states against the oracle's leapfrog_chain_dyn; the test
+    quantity is formed from kick-drift-kick values that differ from the oracle's in the last bits, so a chain
+    whose dot product passes zero within rounding may stop one step apart: such chains (none or very few) are
+    left out of the state comparison."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(8)
+    D, pot, op, h = _dyn_case(P, case, rs)
+    N, L = 333, 40
+    h = 0.15
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.UTURN_STOP | (lib.PER_CHAIN_STEPS if mode == "both" else 0)
+    q0 = rs.standard_normal((D, N))
+    p0 = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+    u = rs.uniform(size=N)
+    steps_in = rs.randint(1, L + 1, size=N).astype(np.int32) if mode == "both" else None
+    qd, pd, ud = as_device(q0, 0, np.float64), as_device(p0, 0, np.float64), as_device(u, 0, np.float64)
+    sd = torch.tensor(steps_in, device="cuda") if mode == "both" else None
+    qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
+    ro, rj, so = empty((N,), np.float64, 0), empty((N,), np.uint8, 0), empty((N,), np.int32, 0)
+    lib.call("pbbi_hmc_iter_dyn", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+             md.data_ptr() if mass else None, sd.data_ptr() if mode == "both" else None, qo.data_ptr(),
+             po.data_ptr(), ro.data_ptr(), rj.data_ptr(), so.data_ptr(), N, N, h, L, flags, 1.0, stream_ptr(0))
+    torch.cuda.synchronize()
+    q_or, p_or = q0.copy(), p0.copy()
+    r_or, rej_or, st_or = orc.hmc_iter_dyn(op, q_or, p_or, u, m, h, L, steps_in=steps_in, uturn=True)
+    st = to_numpy(so)
+    same = st == st_or
+    assert same.mean() > 0.99, (same.mean(), st[:20], st_or[:20])
+    cap = steps_in if mode == "both" else np.full(N, L)
+    assert (st_or < cap).mean() > (0.4 if mode == "uturn" else 0.2) and len(np.unique(st_or)) > 5   # U-turns did end trajectories
+    assert np.array_equal(to_numpy(rj).astype(bool)[same], rej_or[same])
+    assert scaled_err(to_numpy(qo)[:, same], q_or[:, same]) <= RTOL_DENSE
+    assert scaled_err(to_numpy(po)[:, same], p_or[:, same]) <= RTOL_DENSE
 
 
 def test_per_chain_steps_sampling_and_uturn_adaptation(P):
@@ -1869,6 +1908,13 @@ def test_per_chain_steps_sampling_and_uturn_adaptation(P):
     assert np.max(np.abs(x.var(1) * prec - 1.0)) < 0.05
     T = hmc.adaptTrajectoryLength(1.0 / kB, 1.0, iterations=12, max_steps=400)
     assert hmc.integrator.numSteps == int(round(T / 0.05)) and hmc.uturn_steps.shape == (6, N)
+    # the same measurement on the dense MFMA kernel: an isotropic Gaussian of unit frequency turns after
+    # about a quarter to half a period (pi/2 .. pi)
+    Dd, Nd = 24, 4096
+    potd = P.GaussianDense(None, precision=np.eye(Dd), const=0.0)
+    hd = P.HMC(P.Ensemble(Dd, Nd), 1.0, 0.05, None, potential=potd, rng="philox", seed=2, verbose=False)
+    Td = hd.adaptTrajectoryLength(1.0 / kB, 1.0, iterations=8, max_steps=200)
+    assert 1.2 < Td < 3.5 and hd.uturn_steps.max() < 200
     # slowest mode omega = 0.5: its U-turn comes after ~ a quarter period (pi) when started at the mode's
     # edge, later otherwise; faster modes pull the multivariate criterion earlier
     assert 0.5 < T < 2 * np.pi, T
