@@ -783,11 +783,7 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
             a.carry_g = carry;
             a.carry_sel = (uint8_t*)(carry + carry_bytes);
         }
-        if (steps_out) {
-            if (dyn) a.steps_out = steps_out + (size_t)i * N;
-            else hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
-                                    steps_out + (size_t)i * N, N, L);
-        }
+        if (steps_out && dyn) a.steps_out = steps_out + (size_t)i * N;
         // kernels that keep the chain on chip take several iterations per launch
         int chunk = route_fused_iterations(a);
         if (chunk > 1) {  // launches of (nearly) equal length instead of full chunks and a short tail
@@ -795,6 +791,11 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
             chunk = (rem + launches - 1) / launches;
         }
         if (chunk > S - i) chunk = S - i;
+        if (steps_out && !dyn) {  // fixed length: every chain of the iterations this call covers took L steps
+            const int64_t cells = (int64_t)N * (chunk > 1 ? chunk : 1);
+            hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st,
+                               steps_out + (size_t)i * N, cells, L);
+        }
         if (chunk > 1) {
             a.fuse_S = chunk;
             a.fuse_wrap2 = samples_out ? 0 : 1;

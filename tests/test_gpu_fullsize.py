@@ -356,3 +356,30 @@ def test_gemm_path_run_carries_the_gradient_bit_identically(P, lib, D, N, dtype,
     for a, b in zip(one, each):
         assert np.array_equal(a, b)
     assert 0.05 < one[2].mean() < 0.95
+
+
+@pytest.mark.parametrize("kind", ["dense128", "ros32", "diag8"])
+def test_run_dyn_without_length_flags_reports_L_for_every_iteration(P, lib, kind):
+    """pbbi_hmc_run_dyn with neither PBBI_PER_CHAIN_STEPS nor PBBI_UTURN_STOP is pbbi_hmc_run plus a steps
+    array that reads L everywhere -- also for the iterations a fused launch covers (dense Gaussian D = 128,
+    two-lane Rosenbrock), which used to get their first row only."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr, to_numpy
+    N, S, L, h = 300, 7, 4, 0.05
+    if kind == "dense128":
+        D = 128
+        Pm, _ = _stress_problem(D, True)
+        pot = P.GaussianDense(None, precision=Pm, const=0.0)
+    elif kind == "ros32":
+        D, pot = 32, P.Rosenbrock(32)
+    else:
+        D, pot = 8, P.GaussianDiag(np.zeros(8), prec=np.ones(8), const=0.0)
+    st = stream_ptr(0)
+    qd = torch.full((D, N), 1.0, dtype=torch.float64, device="cuda") + 0.1 * torch.randn((D, N), dtype=torch.float64,
+                                                                                        device="cuda")
+    samples = empty((S, D, N), np.float64, 0)
+    steps = torch.full((S, N), -7, dtype=torch.int32, device="cuda")
+    lib.call("pbbi_hmc_run_dyn", pot.handle, 0, qd.data_ptr(), None, samples.data_ptr(), None, None, None,
+             steps.data_ptr(), N, N, h, L, S, lib.COMPAT_P_FROM_OLDQ, 3, 0, 0, 1.0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(steps), np.full((S, N), L, dtype=np.int32))
