@@ -46,11 +46,26 @@ struct SepPrm {
     int harmonic;  // k_sep_exact_hmc: U = 0.5 sum k q^2 in the harmonic potential's own operation order
 };
 
+// Where the iterations of a fused run put their results (pbbi_hmc_run, IterArgs::fuse_*; as Ros2Run in
+// kernels_lane2.hip): iteration k of the launch writes position slab (slab0 + k), modulo 2 for a burn-in's
+// two scratch slabs, momentum slab k, ratio / reject rows k.
+struct SepRun {
+    int S;            // iterations in this launch (1: plain pbbi_hmc_iter semantics)
+    int wrap2;
+    int64_t slab0;    // index of the first iteration's position slab
+    int64_t slab;     // elements per slab (D * N)
+    double* q_base;   // slab 0 of the position slabs
+};
+
 // FULL: D is a multiple of 16, every dim of every part exists: no guards (as scalar branches they
 // put an s_waitcnt between consecutive loads / stores)
+// run.S > 1: the workgroup keeps its 64 chains in registers for run.S consecutive iterations -- the
+// kernel is bound by HBM, and a chain that is not re-read every iteration moves 3 instead of 4 slabs.
+// Every iteration ends with the position it stored (x + mu, or the old position of a rejected chain) and
+// starts the next one from that value minus mu, exactly what a launch of its own would load and form.
 template <bool UNIT, bool FULL, int METHOD>
-__global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
-    __shared__ double dH[MAXG][64];
+__global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm, SepRun run) {
+    __shared__ double dH[2][MAXG][64];  // by iteration parity: one barrier per iteration is enough
     const int c = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
     const int G = (int)(blockDim.x >> 6);
@@ -67,8 +82,6 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): rows past D read 0 / drop stores
     const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
     const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0 + (int64_t)d0 * prm.ldn_in, D - d0, prm.ldn_in, prm.N, n0, 8);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return FULL || d0 + j < D; };  // wave-uniform
     auto ld = [&](__amdgpu_buffer_rsrc_t r, int j) { return buf_load<double>(r, vo, (uint32_t)j * rin); };
     auto st = [&](__amdgpu_buffer_rsrc_t r, int j, double x) { buf_store(r, vo, (uint32_t)j * rout, x); };
@@ -88,11 +101,25 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
         q[j] = exists(j) ? x : 0.0;
     }
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+#pragma nounroll
+    for (int kf = 0; kf < run.S; ++kf) {
+    const uint64_t iter_k = prm.iter + (uint64_t)kf;
+    // this iteration's view: where a rejected chain re-reads its position, where the results go
+    const int64_t s_out = run.wrap2 ? ((run.slab0 + kf) & 1) : run.slab0 + kf;
+    const int64_t s_prev = run.wrap2 ? ((run.slab0 + kf - 1) & 1) : run.slab0 + kf - 1;
+    const double* q_in_k = kf > 0 ? run.q_base + s_prev * run.slab : prm.q_in;
+    const int64_t ld_in_k = kf > 0 ? prm.ldn_out : prm.ldn_in;
+    double* q_out_k = run.S > 1 ? run.q_base + s_out * run.slab : prm.q_out;
+    double* p_out_k = (prm.p_out && run.S > 1) ? prm.p_out + (int64_t)kf * run.slab : prm.p_out;
+    const uint32_t rin_k = 8u * (uint32_t)ld_in_k;
+    const __amdgpu_buffer_rsrc_t bq_k = buf_make_rows(q_in_k + n0 + (int64_t)d0 * ld_in_k, D - d0, ld_in_k, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(q_out_k + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(p_out_k + n0 + (int64_t)d0 * prm.ldn_out, D - d0, prm.ldn_out, prm.N, n0, 8);
     auto draw = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // this part's group of 16 dims: blocks (part<<2)|r
             float z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((part << 2) | r), z);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
         }
@@ -162,19 +189,19 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
     }
 
     // oldH - newH: the parts' shares summed in part order (the same value in every wave)
-    dH[part][c] = oldE - energy();
+    dH[kf & 1][part][c] = oldE - energy();
     __syncthreads();
     double dsum = 0.0;
-    for (int g = 0; g < G; ++g) dsum += dH[g][c];
+    for (int g = 0; g < G; ++g) dsum += dH[kf & 1][g][c];
     const double ratio = exp(dsum * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
-    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const double u = prm.rng ? rng_uniform(prm.seed, iter_k, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
     // back to positions: q = x + mu, or the untouched old position for a rejected chain (:175)
 #pragma unroll
     for (int j = 0; j < DL; ++j) q[j] = q[j] + mu[j];
     if (reject) {
 #pragma unroll
-        for (int j = 0; j < DL; ++j) q[j] = ld(bq, j);
+        for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq_k, vo, (uint32_t)j * rin_k);
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -194,10 +221,18 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm) {
             for (int j = 0; j < DL; ++j) st(bpo, j, v[j]);
         }
         if (part == 0) {
-            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
-            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+            if (prm.ratio_out) prm.ratio_out[(int64_t)kf * prm.N + n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[(int64_t)kf * prm.N + n0 + c] = reject ? 1 : 0;
         }
     }
+    if (kf + 1 < run.S) {  // the next iteration's x, from the position just stored (what a launch would load)
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const double x = q[j] - mu[j];
+            q[j] = exists(j) ? x : 0.0;
+        }
+    }
+    }  // kf
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,12 +430,14 @@ int sepn_hmc_iter(const IterArgs& a) {
     const int G = (pot->D + DL - 1) / DL;
     const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
     const bool full = (pot->D % DL == 0);
+    SepRun run{1, 0, 0, (int64_t)pot->D * a.N, (double*)a.q_out};
+    if (a.fuse_S > 1) run = SepRun{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)pot->D * a.N, (double*)a.fuse_q_base};
 #define SEP_LAUNCH(U_, F_)                                                                              \
     {                                                                                                   \
         if (a.method == PBBI_LEAPFROG)                                                                  \
-            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_LEAPFROG>), grid, block, 0, a.stream, prm);      \
+            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_LEAPFROG>), grid, block, 0, a.stream, prm, run); \
         else                                                                                            \
-            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_STORMER_VERLET>), grid, block, 0, a.stream, prm);\
+            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_STORMER_VERLET>), grid, block, 0, a.stream, prm, run);\
     }
     if (a.mass) {
         if (full) SEP_LAUNCH(false, true) else SEP_LAUNCH(false, false)

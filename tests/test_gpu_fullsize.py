@@ -383,3 +383,41 @@ def test_run_dyn_without_length_flags_reports_L_for_every_iteration(P, lib, kind
              steps.data_ptr(), N, N, h, L, S, lib.COMPAT_P_FROM_OLDQ, 3, 0, 0, 1.0, st)
     torch.cuda.synchronize()
     assert np.array_equal(to_numpy(steps), np.full((S, N), L, dtype=np.int32))
+
+
+@pytest.mark.parametrize("D,mass,method,harmonic", [(64, False, 0, False), (100, True, 0, False), (48, True, 1, True),
+                                                     (256, False, 0, False)])
+def test_separable_run_fused_bit_identically(P, lib, D, mass, method, harmonic):
+    """k_sep_hmc (harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA) keeps a workgroup's chains in
+    registers for up to 16 iterations of a run.  One run of S iterations == S runs of one, bit for bit
+    (positions are re-formed from the stored value minus the mean, as a launch of its own does), with
+    rejections, ragged N, masses, both integrators; the burn-in form ends in the same state."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    N, h, L, S, seed, chain0, iter0 = 1003, 0.9, 3, 19, 6, 40, 3
+    rs = np.random.RandomState(D)
+    prec = rs.uniform(0.5, 2.0, D)
+    pot = P.Harmonic(prec) if harmonic else P.GaussianDiag(rs.standard_normal(D), prec=prec, const=0.0)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    st = stream_ptr(0)
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA
+    q0 = rs.standard_normal((D, N))
+
+    def run(s_per_call, record=True):
+        qd = as_device(q0, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, method, qd.data_ptr(), md.data_ptr() if mass else None,
+                     samples[i].data_ptr() if record else None, momenta[i].data_ptr() if record else None,
+                     reject[i].data_ptr() if record else None, ratio[i].data_ptr() if record else None,
+                     N, N, h, L, min(s_per_call, S - i), flags, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one, each = run(S), run(1)
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.02 < one[2].mean() < 0.98
+    assert np.array_equal(run(S, record=False)[4], one[4])
