@@ -143,7 +143,13 @@ int route_hmc(const IterArgs& a) {
 // consecutive iterations of pbbi_hmc_run that ONE route_hmc call may cover (IterArgs::fuse_*)
 int route_fused_iterations(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
-    if (pot->kind == KIND_CUSTOM || is_big(pot)) return 1;
+    if (is_big(pot) && pot->kind != KIND_CUSTOM) return 1;
+    if (pot->kind == KIND_CUSTOM) {
+        // plugins (PBBI_PLUGIN_ABI >= 4) take the iterations of a run several at a time: their register
+        // kernels keep the chain and its potential energy on chip, the workspace kernels unroll the call
+        static const int fuse = getenv("PBBI_FUSE_ITERS") ? atoi(getenv("PBBI_FUSE_ITERS")) : 16;
+        return (fuse > 1 && a.rng && a.N > 0 && !pbbi_dyn(a)) ? fuse : 1;
+    }
     if (is_dense(pot)) return dense_fused_iterations(a);
     return lane_fused_iterations(a);
 }

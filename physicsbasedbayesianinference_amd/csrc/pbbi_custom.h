@@ -210,6 +210,11 @@ struct HmcPrm {
     double kT;
     const T* prm;
     T *Wq, *Wv, *Wa, *Wg;
+    // fused run (IterArgs::fuse_*, register kernels): iteration k of the call writes position slab
+    // (fuse_slab0 + k) of fuse_q_base (modulo 2 when fuse_wrap2), momentum slab k, ratio / reject rows k
+    int fuse_S, fuse_wrap2;
+    int64_t fuse_slab0, fuse_slab;
+    T* fuse_q_base;
 };
 
 template <int METHOD, bool UNIT, bool KDK = false>
@@ -492,11 +497,25 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
     const T m = UNIT ? T(1) : prm.mass[n];
     const uint64_t chain = prm.chain0 + (uint64_t)n;
     const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
-    const T* qin = prm.q_in + n;
     const T* pin = prm.rng ? nullptr : prm.p_in + n;
     Vec q, v;
 #pragma unroll
-    for (int j = 0; j < RD; ++j) q[j] = qin[(int64_t)j * prm.ldn_in];
+    for (int j = 0; j < RD; ++j) q[j] = prm.q_in[(int64_t)j * prm.ldn_in + n];
+    // A fused run keeps the chain in these registers for fuse_S iterations; the potential energy of the
+    // position an iteration starts from is the one the previous iteration already evaluated (its proposal's
+    // if it accepted, its own start's if it rejected) and is carried instead of evaluated again -- one call
+    // of the user's potential per iteration instead of two, the same value.
+    T U_cur = T(0);
+    const int nfuse = prm.fuse_S > 1 ? prm.fuse_S : 1;
+#pragma nounroll
+    for (int kf = 0; kf < nfuse; ++kf) {
+    const uint64_t iter_k = prm.iter + (uint64_t)kf;
+    const int64_t s_out = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf) & 1) : prm.fuse_slab0 + kf;
+    const int64_t s_prev = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf - 1) & 1) : prm.fuse_slab0 + kf - 1;
+    const T* qin = (kf > 0 ? prm.fuse_q_base + s_prev * prm.fuse_slab : prm.q_in) + n;
+    const int64_t ld_in = kf > 0 ? prm.ldn_out : prm.ldn_in;
+    T* const q_out_k = nfuse > 1 ? prm.fuse_q_base + s_out * prm.fuse_slab : prm.q_out;
+    T* const p_out_k = (prm.p_out && nfuse > 1) ? prm.p_out + (int64_t)kf * prm.fuse_slab : prm.p_out;
     auto draw = [&]() {
 #pragma unroll
         for (int G = 0; G < (RD + 15) / 16; ++G)
@@ -504,7 +523,7 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
             for (int r = 0; r < 4; ++r) {
                 if (16 * G + r < RD) {
                     float z[4];
-                    rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((G << 2) | r), z);
+                    rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((G << 2) | r), z);
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl) {
                         const int d = 16 * G + r + 4 * sl;
@@ -516,7 +535,7 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
     T u;
     if (prm.rng) {
         draw();
-        u = (T)rng_uniform(prm.seed, prm.iter, chain);
+        u = (T)rng_uniform(prm.seed, iter_k, chain);
     } else {
 #pragma unroll
         for (int j = 0; j < RD; ++j) v[j] = pin[(int64_t)j * prm.ldn_in];
@@ -525,7 +544,8 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
     T pp = T(0);
 #pragma unroll
     for (int j = 0; j < RD; ++j) pp += v[j] * v[j];
-    const T oldH = T(0.5) * pp / m + user::potential(q, RD, prm.prm);  // src/HMC.py:100-102
+    const T U_old = kf > 0 ? U_cur : user::potential(q, RD, prm.prm);
+    const T oldH = T(0.5) * pp / m + U_old;  // src/HMC.py:100-102
     if constexpr (!UNIT) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) v[j] = v[j] / m;
@@ -538,12 +558,14 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
     T pp1 = T(0);
 #pragma unroll
     for (int j = 0; j < RD; ++j) pp1 += v[j] * v[j];
-    const T newH = T(0.5) * pp1 / m + user::potential(q, RD, prm.prm);
+    const T U_new = user::potential(q, RD, prm.prm);
+    const T newH = T(0.5) * pp1 / m + U_new;
     const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
     const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+    U_cur = reject ? U_old : U_new;
     if (reject) {
 #pragma unroll
-        for (int j = 0; j < RD; ++j) q[j] = qin[(int64_t)j * prm.ldn_in];  // :175
+        for (int j = 0; j < RD; ++j) q[j] = qin[(int64_t)j * ld_in];  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -557,13 +579,14 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < RD; ++j) prm.q_out[(int64_t)j * prm.ldn_out + n] = q[j];
+    for (int j = 0; j < RD; ++j) q_out_k[(int64_t)j * prm.ldn_out + n] = q[j];
     if (prm.p_out) {
 #pragma unroll
-        for (int j = 0; j < RD; ++j) prm.p_out[(int64_t)j * prm.ldn_out + n] = v[j];
+        for (int j = 0; j < RD; ++j) p_out_k[(int64_t)j * prm.ldn_out + n] = v[j];
     }
-    if (prm.ratio_out) prm.ratio_out[n] = ratio;
-    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+    if (prm.ratio_out) prm.ratio_out[(int64_t)kf * prm.N + n] = ratio;
+    if (prm.reject_out) prm.reject_out[(int64_t)kf * prm.N + n] = reject ? 1 : 0;
+    }  // kf
 }
 
 template <int METHOD, bool UNIT>
@@ -611,7 +634,8 @@ int reg_hmc(const IterArgs* a) {
                    (T*)a->q_out, (T*)a->p_out, (T*)a->ratio_out, a->reject_out,
                    a->N, a->ldn_in, a->ldn_out, (T)a->h, a->L, pot->D, a->flags, a->rng,
                    a->seed, a->iter, a->chain0, a->kT, (const T*)pot->d_params, nullptr, nullptr,
-                   nullptr, nullptr};
+                   nullptr, nullptr, a->fuse_S, a->fuse_wrap2, a->fuse_slab0, (int64_t)pot->D * a->N,
+                   (T*)a->fuse_q_base};
         if constexpr (KDK) {  // Leapfrog only
             if (a->mass == nullptr)
                 hipLaunchKernelGGL((k_custom_reg_hmc<PBBI_LEAPFROG, true, true>),
@@ -662,6 +686,24 @@ int pbbi_plugin_hmc_iter(const IterArgs* a) {
     if (REG_OK_KDK && pot->D == RD && (a->flags & PBBI_KDK_FMA) && a->method == PBBI_LEAPFROG)
         return reg_hmc<REG_OK_KDK, true>(a);
     if (REG_OK && pot->D == RD) return reg_hmc<REG_OK>(a);
+    if (a->fuse_S > 1) {  // the workspace kernels take one iteration per launch: unroll the fused call here
+        const int64_t slab_e = (int64_t)pot->D * a->N;
+        for (int k = 0; k < a->fuse_S; ++k) {
+            IterArgs it = *a;
+            const int64_t s_out = a->fuse_wrap2 ? ((a->fuse_slab0 + k) & 1) : a->fuse_slab0 + k;
+            const int64_t s_prev = a->fuse_wrap2 ? ((a->fuse_slab0 + k - 1) & 1) : a->fuse_slab0 + k - 1;
+            it.fuse_S = 1;
+            if (k > 0) { it.q_in = (const T*)a->fuse_q_base + s_prev * slab_e; it.ldn_in = a->ldn_out; }
+            it.q_out = (T*)a->fuse_q_base + s_out * slab_e;
+            if (a->p_out) it.p_out = (T*)a->p_out + (int64_t)k * slab_e;
+            if (a->ratio_out) it.ratio_out = (T*)a->ratio_out + (int64_t)k * a->N;
+            if (a->reject_out) it.reject_out = a->reject_out + (int64_t)k * a->N;
+            it.iter = a->iter + (uint64_t)k;
+            if (k > 0) it.scratch_used = nullptr;
+            if (int rc = pbbi_plugin_hmc_iter(&it)) return rc;
+        }
+        return 0;
+    }
     Scratch ws(*a);
     const size_t slab = (size_t)pot->D * a->N * sizeof(T);
     T *Wq = (T*)ws.get(slab), *Wv = (T*)ws.get(slab), *Wa = (T*)ws.get(slab), *Wg = (T*)ws.get(slab);

@@ -10,7 +10,7 @@
 enum { KIND_HARMONIC = 0, KIND_GAUSS_DIAG = 1, KIND_GAUSS_DENSE = 2, KIND_ROSENBROCK = 3, KIND_CUSTOM = 4 };
 
 // layout version of the structs a user-potential plugin (pbbi_custom.h) shares with libpbbi.so
-#define PBBI_PLUGIN_ABI 3
+#define PBBI_PLUGIN_ABI 4  /* 4: plugins honour IterArgs::fuse_* (several iterations of a run per call) */
 
 struct IterArgs;
 struct IntegrateArgs;

@@ -128,8 +128,12 @@ def compile_plugin(source, dtype="float64", verbose=False, D=None):
     with open(src, "w") as f:
         f.write(tu)
     tmp = so + f".tmp{os.getpid()}"
+    # (the -mllvm switches: the register kernels loop over the iterations of a fused run around a fully
+    #  unrolled body; left alone hipcc hoists that body's invariants out of the loop and spills them --
+    #  csrc/Makefile, FLAGS_kernels_lane2)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
+           "-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills",
+           "-mllvm", "-amdgpu-use-amdgpu-trackers=1", f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -421,3 +421,53 @@ def test_separable_run_fused_bit_identically(P, lib, D, mass, method, harmonic):
         assert np.array_equal(a, b)
     assert 0.02 < one[2].mean() < 0.98
     assert np.array_equal(run(S, record=False)[4], one[4])
+
+
+@pytest.mark.parametrize("case", ["quartic9", "quartic9_ad", "quartic9_f32", "quartic48_workspace", "logistic"])
+def test_custom_potential_run_fused_bit_identically(P, lib, case):
+    """User potentials (plugin kernels): pbbi_hmc_run hands the plugin 16 iterations at a time; the register
+    kernels keep the chain and its potential energy on chip (one evaluation of the user's potential per
+    iteration instead of two), the workspace kernels unroll the call.  One run of S iterations == S runs of
+    one, bit for bit, with rejections, masses, ragged N; burn-in form ends in the same state."""
+    import torch
+    from physicsbasedbayesianinference_amd import CustomPotential
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    from custom_sources import LOGISTIC, QUARTIC, QUARTIC_AD
+    rs = np.random.RandomState(3)
+    npdt, h = np.float64, 0.35
+    if case == "quartic9":
+        D, pot = 9, CustomPotential(9, QUARTIC, [1.0, 0.5])
+    elif case == "quartic9_ad":
+        D, pot = 9, CustomPotential(9, QUARTIC_AD, [1.0, 0.5])
+    elif case == "quartic9_f32":
+        D, pot, npdt = 9, CustomPotential(9, QUARTIC, [1.0, 0.5], dtype="float32"), np.float32
+    elif case == "quartic48_workspace":
+        D, pot, h = 48, CustomPotential(48, QUARTIC, [1.0, 0.5]), 0.2
+    else:
+        M, D = 64, 6
+        X = rs.standard_normal((M, D))
+        y = (rs.uniform(size=M) < 0.5).astype(np.float64)
+        pot, h = CustomPotential(D, LOGISTIC, np.concatenate([[float(M)], X.ravel(), y, [1.0]])), 0.25
+    N, L, S, seed, chain0, iter0 = 777, 4, 21, 8, 5, 2
+    m = 1.0 + (np.arange(N) % 3) * 0.5
+    md = as_device(m, 0, npdt)
+    st = stream_ptr(0)
+    q0 = rs.standard_normal((D, N))
+
+    def run(s_per_call, record=True):
+        qd = as_device(q0, 0, npdt)
+        samples, momenta = empty((S, D, N), npdt, 0), empty((S, D, N), npdt, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), npdt, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr(),
+                     samples[i].data_ptr() if record else None, momenta[i].data_ptr() if record else None,
+                     reject[i].data_ptr() if record else None, ratio[i].data_ptr() if record else None,
+                     N, N, h, L, min(s_per_call, S - i), lib.COMPAT_P_FROM_OLDQ, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one, each = run(S), run(1)
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.02 < one[2].mean() < 0.98
+    assert np.array_equal(run(S, record=False)[4], one[4])
