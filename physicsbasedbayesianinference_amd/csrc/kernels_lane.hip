@@ -730,13 +730,16 @@ int lane_dyn_hmc_iter(const IterArgs& a) {
 }
 
 int lane_fused_iterations(const IterArgs& a) {
-    // kernels that keep a chain in registers across iterations: the two-lane Rosenbrock kernel and the
-    // parts-in-waves separable kernel in its kick-drift-kick form (the order of lane_hmc_iter's dispatch)
+    // kernels that keep a chain in registers across iterations: the two-lane Rosenbrock kernel, its 4 / 8-lane
+    // form and the parts-in-waves separable kernel, the latter two in their kick-drift-kick forms (the order
+    // of lane_hmc_iter's dispatch)
     static const int fuse = getenv("PBBI_FUSE_ITERS") ? atoi(getenv("PBBI_FUSE_ITERS")) : 16;
     static const bool no_lane2 = (getenv("PBBI_NO_LANE2") != nullptr);
     static const bool no_sep_fuse = (getenv("PBBI_NO_SEP_FUSE") != nullptr);  // A/B switch
     if (fuse <= 1 || !a.rng || a.N == 0 || pbbi_dyn(a)) return 1;
     if (sepn_applies(a)) return no_sep_fuse ? 1 : fuse;
+    if (sepx_applies(a) || rosgx_applies(a)) return 1;   // (reference-order forms of those layouts: one iteration per launch)
+    if (rosg_applies(a)) return no_sep_fuse ? 1 : fuse;  // Rosenbrock 32 < D <= 128, kick-drift-kick form
     if (no_lane2 || !lane2_applies(a) || streams(a.pot)) return 1;
     if (check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) != PBBI_OK) return 1;
     return fuse;

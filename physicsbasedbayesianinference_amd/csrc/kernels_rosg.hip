@@ -46,8 +46,21 @@ __device__ __forceinline__ double part_sum(double x) {  // sum over the G lanes 
     return x;
 }
 
+// Where the iterations of a fused run put their results (pbbi_hmc_run, IterArgs::fuse_*; as Ros2Run in
+// kernels_lane2.hip).
+struct RosgRun {
+    int S;            // iterations in this launch (1: plain pbbi_hmc_iter semantics)
+    int wrap2;        // position slabs alternate between slab 0 and 1 of q_base (burn-in)
+    int64_t slab0;    // index of the first iteration's position slab
+    int64_t slab;     // elements per slab (D * N)
+    double* q_base;   // slab 0 of the position slabs
+};
+
+// run.S > 1: the wave keeps its chains in registers for run.S consecutive iterations, and the potential
+// energy of the position an iteration starts from is the one the previous iteration formed (carried in a
+// register, the same value), as in k_ros2_hmc.
 template <int G, bool UNIT, bool FULL, int METHOD>
-__global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
+__global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm, RosgRun run) {
     constexpr int CPW = 64 / G;  // chains per wave
     const int lane = threadIdx.x;
     const int part = lane / CPW, c = lane % CPW;
@@ -64,8 +77,6 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
     // descriptors bounded to the array (pbbi_buf.h::buf_make_rows): rows past D read 0 / drop stores
     const __amdgpu_buffer_rsrc_t bq = buf_make_rows(prm.q_in + n0, D, prm.ldn_in, prm.N, n0, 8);
     const __amdgpu_buffer_rsrc_t bp = buf_make_rows(prm.p_in + n0, D, prm.ldn_in, prm.N, n0, 8);
-    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(prm.q_out + n0, D, prm.ldn_out, prm.N, n0, 8);
-    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(prm.p_out + n0, D, prm.ldn_out, prm.N, n0, 8);
     auto exists = [&](int j) { return FULL ? true : DL * part + j < D; };
     auto has_next = [&](int j) {  // dim 16*part + j has a right neighbour
         if constexpr (FULL) return j + 1 < DL ? true : part + 1 < G;
@@ -76,11 +87,26 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
 #pragma unroll
     for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);
     const double pstd = prm.rng ? sqrt(m * prm.kT) : 1.0;  // src/ensemble.py:88
+    double U_carry = 0.0;  // U at the position in q[], from the second iteration of the launch on
+#pragma nounroll
+    for (int kf = 0; kf < run.S; ++kf) {
+    const uint64_t iter_k = prm.iter + (uint64_t)kf;
+    const int64_t s_out = run.wrap2 ? ((run.slab0 + kf) & 1) : run.slab0 + kf;
+    const int64_t s_prev = run.wrap2 ? ((run.slab0 + kf - 1) & 1) : run.slab0 + kf - 1;
+    const double* q_in_k = kf > 0 ? run.q_base + s_prev * run.slab : prm.q_in;
+    const int64_t ld_in_k = kf > 0 ? prm.ldn_out : prm.ldn_in;
+    double* q_out_k = run.S > 1 ? run.q_base + s_out * run.slab : prm.q_out;
+    double* p_out_k = (prm.p_out && run.S > 1) ? prm.p_out + (int64_t)kf * run.slab : prm.p_out;
+    const uint32_t rin_k = 8u * (uint32_t)ld_in_k;
+    const uint32_t vin_k = 8u * (uint32_t)cc + (uint32_t)(DL * part) * rin_k;
+    const __amdgpu_buffer_rsrc_t bq_k = buf_make_rows(q_in_k + n0, D, ld_in_k, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bqo = buf_make_rows(q_out_k + n0, D, prm.ldn_out, prm.N, n0, 8);
+    const __amdgpu_buffer_rsrc_t bpo = buf_make_rows(p_out_k + n0, D, prm.ldn_out, prm.N, n0, 8);
     auto draw = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // this part's group of 16 dims: blocks (part<<2)|r
             float z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((part << 2) | r), z);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
         }
@@ -96,9 +122,15 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
     auto from_next = [&](double x) { return __shfl_down(x, CPW, 64); };
     auto from_prev = [&](double x) { return __shfl_up(x, CPW, 64); };
     // H = 0.5 p.p / m + (sum b t^2 + sum (a - q)^2) / s, summed over the chain's parts
-    auto hamiltonian = [&]() {
+    auto kinetic = [&]() {
+        double pp = 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) pp = fma(v[j], v[j], pp);
+        return 0.5 * part_sum<G>(pp) / m;
+    };
+    auto potential = [&]() {
         const double q_ext = from_next(q[0]);
-        double pp = 0.0, s1 = 0.0, s2 = 0.0;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int j = 0; j < DL; ++j) {
             const double qn = (j + 1 < DL) ? q[(j + 1) & (DL - 1)] : q_ext;
@@ -108,9 +140,8 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
             const bool hn = has_next(j);
             s1 = hn ? n1 : s1;
             s2 = hn ? n2 : s2;
-            pp = fma(v[j], v[j], pp);
         }
-        return 0.5 * part_sum<G>(pp) / m + part_sum<G>(s1 + s2) * prm.inv_s;
+        return part_sum<G>(s1 + s2) * prm.inv_s;
     };
     // v_j += kk * (-g_j): kernels_lane2.hip::kdk_kick with the boundary terms from the neighbour parts
     auto kick = [&](double kk) {
@@ -135,7 +166,8 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
         }
     };
 
-    const double oldH = hamiltonian();
+    const double U_old = kf > 0 ? U_carry : potential();
+    const double oldH = kinetic() + U_old;
     // ---- Leapfrog, kick-drift-kick: vh = v + a0 h/2;  L x { q += vh h; vh += a(q) h }, last kick half
     const double h = prm.h, hm = UNIT ? h : h / m, hhm = 0.5 * hm;
     if constexpr (!UNIT) {
@@ -167,13 +199,15 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] * m;  // p = v*m
     }
-    const double newH = hamiltonian();
+    const double U_new = potential();
+    const double newH = kinetic() + U_new;
     const double ratio = exp((oldH - newH) * pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
-    const double u = prm.rng ? rng_uniform(prm.seed, prm.iter, chain) : prm.u_in[n0 + cc];
+    const double u = prm.rng ? rng_uniform(prm.seed, iter_k, chain) : prm.u_in[n0 + cc];
     const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    U_carry = reject ? U_old : U_new;  // (all lanes of a chain decide alike)
     if (reject) {
 #pragma unroll
-        for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq, vin, (uint32_t)j * rin);  // :175
+        for (int j = 0; j < DL; ++j) q[j] = buf_load<double>(bq_k, vin_k, (uint32_t)j * rin_k);  // :175
         if (prm.p_out) {
             if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
@@ -193,10 +227,11 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm) {
             for (int j = 0; j < DL; ++j) buf_store(bpo, vout, (uint32_t)j * rout, v[j]);
         }
         if (part == 0) {
-            if (prm.ratio_out) prm.ratio_out[n0 + c] = ratio;
-            if (prm.reject_out) prm.reject_out[n0 + c] = reject ? 1 : 0;
+            if (prm.ratio_out) prm.ratio_out[(int64_t)kf * prm.N + n0 + c] = ratio;
+            if (prm.reject_out) prm.reject_out[(int64_t)kf * prm.N + n0 + c] = reject ? 1 : 0;
         }
     }
+    }  // kf
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,10 +416,12 @@ template <int G>
 void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
     constexpr int CPW = 64 / G;
     const dim3 grid((unsigned)((a.N + CPW - 1) / CPW)), block(64);
+    RosgRun run{1, 0, 0, (int64_t)a.pot->D * a.N, (double*)a.q_out};
+    if (a.fuse_S > 1) run = RosgRun{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)a.pot->D * a.N, (double*)a.fuse_q_base};
 #define ROSG_LAUNCH(U_, M_)                                                                          \
     {                                                                                                \
-        if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true, M_>), grid, block, 0, a.stream, prm);  \
-        else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false, M_>), grid, block, 0, a.stream, prm);      \
+        if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true, M_>), grid, block, 0, a.stream, prm, run);  \
+        else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false, M_>), grid, block, 0, a.stream, prm, run);      \
     }
     if (a.method == PBBI_LEAPFROG) {
         if (a.mass) ROSG_LAUNCH(false, PBBI_LEAPFROG) else ROSG_LAUNCH(true, PBBI_LEAPFROG)

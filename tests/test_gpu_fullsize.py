@@ -471,3 +471,38 @@ def test_custom_potential_run_fused_bit_identically(P, lib, case):
         assert np.array_equal(a, b)
     assert 0.02 < one[2].mean() < 0.98
     assert np.array_equal(run(S, record=False)[4], one[4])
+
+
+@pytest.mark.parametrize("D,mass,method", [(64, False, 0), (100, True, 0), (128, False, 0), (24, True, 1)])
+def test_rosenbrock_multilane_run_fused_bit_identically(P, lib, D, mass, method):
+    """k_rosg_hmc (Rosenbrock, 4 / 8 lanes per chain, PBBI_KDK_FMA; Stormer-Verlet from D = 17) takes up to 16
+    iterations of a run per launch and carries U of the chain's position between them.  One run of S
+    iterations == S runs of one, bit for bit, with rejections, ragged N, masses; burn-in ends alike."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    N, h, L, S, seed, chain0, iter0 = 501, 0.05, 6, 19, 9, 11, 4
+    rs = np.random.RandomState(D)
+    pot = P.Rosenbrock(D)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    st = stream_ptr(0)
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.KDK_FMA
+    q0 = 1.0 + 0.3 * rs.standard_normal((D, N))
+
+    def run(s_per_call, record=True):
+        qd = as_device(q0, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, method, qd.data_ptr(), md.data_ptr() if mass else None,
+                     samples[i].data_ptr() if record else None, momenta[i].data_ptr() if record else None,
+                     reject[i].data_ptr() if record else None, ratio[i].data_ptr() if record else None,
+                     N, N, h, L, min(s_per_call, S - i), flags, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one, each = run(S), run(1)
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.02 < one[2].mean() < 0.98
+    assert np.array_equal(run(S, record=False)[4], one[4])
