@@ -207,6 +207,15 @@ __device__ __forceinline__ T hamiltonian(const Pot& pot, const T (&q)[DMAX], con
     return T(0.5) * pp / m + pot.U(q);
 }
 
+// 0.5 p.p / m: hamiltonian's first term (the two are added in the same order there and in k_lane_hmc)
+template <typename T, int DMAX>
+__device__ __forceinline__ T kinetic(const T (&p)[DMAX], T m) {
+    T pp = T(0);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) pp += p[d] * p[d];
+    return T(0.5) * pp / m;
+}
+
 // momentum draw of one chain: one Philox block per four dims (RNG contract, include/pbbi.h)
 template <typename T, int DMAX>
 __device__ __forceinline__ void draw_momentum(T (&p)[DMAX], int D, uint64_t seed, uint64_t iter,
@@ -245,8 +254,16 @@ struct HmcPrm {
     int L, D, flags, rng;
     uint64_t seed, iter, chain0;
     double kT;
+    // fused run (IterArgs::fuse_*; k_lane_hmc, D <= 16): iteration k of the launch writes position slab
+    // (fuse_slab0 + k) of fuse_q_base (modulo 2 when fuse_wrap2), momentum slab k, ratio / reject rows k
+    int fuse_S, fuse_wrap2;
+    int64_t fuse_slab0, fuse_slab;
+    T* fuse_q_base;
 };
 
+// fuse_S > 1 (small chains, D <= 16: the launch, not the arithmetic, is what an iteration costs): the lane
+// keeps its chain for fuse_S consecutive iterations of the run, and the potential energy of the position an
+// iteration starts from is the one the previous iteration evaluated (carried, the same value).
 template <typename T, typename Pot, int DMAX, int METHOD, bool FULL, bool UNIT>
 __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const int64_t n0 = (int64_t)blockIdx.x * BLOCK;  // block-uniform base chain
@@ -261,56 +278,74 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
     const uint32_t rout = (uint32_t)prm.ldn_out * (uint32_t)sizeof(T);
     const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q_in, D, prm.ldn_in, prm.N, n0);
     const __amdgpu_buffer_rsrc_t bp = rows_rsrc<T, FULL>(prm.p_in, D, prm.ldn_in, prm.N, n0);
-    const __amdgpu_buffer_rsrc_t bqo = rows_rsrc<T, FULL>(prm.q_out, D, prm.ldn_out, prm.N, n0);
-    const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(prm.p_out, D, prm.ldn_out, prm.N, n0);
     const double pstd = prm.rng ? sqrt((double)m * prm.kT) : 1.0;  // src/ensemble.py:88
 
     T q[DMAX], p[DMAX], v[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, rin, d, D);
-    T u;
-    if (prm.rng) {
-        draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
-        u = (T)rng_uniform(prm.seed, prm.iter, chain);
-    } else {
+    T U_cur = T(0);
+    const int nfuse = (DMAX <= 16 && prm.fuse_S > 1) ? prm.fuse_S : 1;
+#pragma nounroll
+    for (int kf = 0; kf < nfuse; ++kf) {
+        const uint64_t iter_k = prm.iter + (uint64_t)kf;
+        // this iteration's view: where a rejected chain re-reads its position, where the results go
+        const int64_t s_out = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf) & 1) : prm.fuse_slab0 + kf;
+        const int64_t s_prev = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf - 1) & 1) : prm.fuse_slab0 + kf - 1;
+        const T* q_in_k = kf > 0 ? prm.fuse_q_base + s_prev * prm.fuse_slab : prm.q_in;
+        const int64_t ld_in_k = kf > 0 ? prm.ldn_out : prm.ldn_in;
+        T* q_out_k = nfuse > 1 ? prm.fuse_q_base + s_out * prm.fuse_slab : prm.q_out;
+        T* p_out_k = (prm.p_out && nfuse > 1) ? prm.p_out + (int64_t)kf * prm.fuse_slab : prm.p_out;
+        const uint32_t rin_k = (uint32_t)ld_in_k * (uint32_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t bq_k = rows_rsrc<T, FULL>(q_in_k, D, ld_in_k, prm.N, n0);
+        const __amdgpu_buffer_rsrc_t bqo = rows_rsrc<T, FULL>(q_out_k, D, prm.ldn_out, prm.N, n0);
+        const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(p_out_k, D, prm.ldn_out, prm.N, n0);
+        T u;
+        if (prm.rng) {
+            draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd);
+            u = (T)rng_uniform(prm.seed, iter_k, chain);
+        } else {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d)
-            p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
-        u = prm.u_in[n];
-    }
-    const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
-    integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
-    const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);  // p -> -p leaves dot(p,p) unchanged
-    const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
-    // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
-    const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
-    if (reject) {
+            for (int d = 0; d < DMAX; ++d)
+                p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
+            u = prm.u_in[n];
+        }
+        const T U_old = kf > 0 ? U_cur : pot.U(q);
+        const T oldH = kinetic<T, DMAX>(p, m) + U_old;
+        integrate_chain<T, Pot, DMAX, METHOD, UNIT>(pot, q, p, v, m, prm.h, prm.L);
+        const T U_new = pot.U(q);
+        const T newH = kinetic<T, DMAX>(p, m) + U_new;  // p -> -p leaves dot(p,p) unchanged
+        const T ratio = exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));  // src/HMC.py:115
+        // mask = u > min(1, ratio); NaN ratio compares False => accepted (src/HMC.py:168-173)
+        const bool reject = (ratio == ratio) && (u > (ratio < T(1) ? ratio : T(1)));
+        U_cur = reject ? U_old : U_new;
+        if (reject) {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d)
-            q[d] = load_row<T, FULL>(bq, voff, rin, d, D);  // :175
-        if (prm.p_out) {
-            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
+            for (int d = 0; d < DMAX; ++d)
+                q[d] = load_row<T, FULL>(bq_k, voff, rin_k, d, D);  // :175
+            if (prm.p_out) {
+                if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {  // :176  p <- oldQ
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d) p[d] = q[d];
-            } else if (prm.rng) {
-                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
-            } else {
+                    for (int d = 0; d < DMAX; ++d) p[d] = q[d];
+                } else if (prm.rng) {
+                    draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd);
+                } else {
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d)
-                    p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
+                    for (int d = 0; d < DMAX; ++d)
+                        p[d] = load_row<T, FULL>(bp, voff, rin, d, D);
+                }
             }
         }
-    }
-#pragma unroll
-    for (int d = 0; d < DMAX; ++d)
-        store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
-    if (prm.p_out) {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-            store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
+            store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
+        if (prm.p_out) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
+        }
+        if (prm.ratio_out) prm.ratio_out[(int64_t)kf * prm.N + n] = ratio;
+        if (prm.reject_out) prm.reject_out[(int64_t)kf * prm.N + n] = reject ? 1 : 0;
     }
-    if (prm.ratio_out) prm.ratio_out[n] = ratio;
-    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
 }
 
 // ---- per-chain trajectory lengths (PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP, include/pbbi.h) -------
@@ -602,7 +637,8 @@ int launch_hmc(const IterArgs& a) {
     HmcPrm<T> prm{(const T*)a.q_in, (const T*)a.p_in, (const T*)a.u_in, (const T*)a.mass,
                   (T*)a.q_out, (T*)a.p_out, (T*)a.ratio_out, a.reject_out,
                   a.N, a.ldn_in, a.ldn_out, (T)a.h, a.L, pot->D, a.flags, a.rng,
-                  a.seed, a.iter, a.chain0, a.kT};
+                  a.seed, a.iter, a.chain0, a.kT, a.fuse_S, a.fuse_wrap2, a.fuse_slab0,
+                  (int64_t)pot->D * a.N, (T*)a.fuse_q_base};
     const dim3 grid = grid_for(a.N);
     with_dmax(pot->D, [&](auto dm) {
         constexpr int DM = decltype(dm)::value;
@@ -740,9 +776,12 @@ int lane_fused_iterations(const IterArgs& a) {
     if (sepn_applies(a)) return no_sep_fuse ? 1 : fuse;
     if (sepx_applies(a) || rosgx_applies(a)) return 1;   // (reference-order forms of those layouts: one iteration per launch)
     if (rosg_applies(a)) return no_sep_fuse ? 1 : fuse;  // Rosenbrock 32 < D <= 128, kick-drift-kick form
-    if (no_lane2 || !lane2_applies(a) || streams(a.pot)) return 1;
+    if (rosn_applies(a) || streams(a.pot)) return 1;
     if (check_ld(a.pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out) != PBBI_OK) return 1;
-    return fuse;
+    if (!no_lane2 && lane2_applies(a)) return fuse;
+    // the plain chain-per-lane kernel: small chains (D <= 16, fp64), where the launch is most of an iteration
+    static const bool no_lane_fuse = (getenv("PBBI_NO_LANE_FUSE") != nullptr);  // A/B switch
+    return (!no_lane_fuse && a.pot->dtype == PBBI_F64 && a.pot->D <= 16) ? fuse : 1;
 }
 int lane_integrate(const IntegrateArgs& a) {
     if (streams(a.pot)) return stream_integrate(a);

@@ -506,3 +506,45 @@ def test_rosenbrock_multilane_run_fused_bit_identically(P, lib, D, mass, method)
         assert np.array_equal(a, b)
     assert 0.02 < one[2].mean() < 0.98
     assert np.array_equal(run(S, record=False)[4], one[4])
+
+
+@pytest.mark.parametrize("kind,D,mass,method,h", [("diag", 8, False, 0, 0.9), ("harm", 3, True, 1, 0.7),
+                                                  ("ros", 12, True, 0, 0.06), ("diag", 16, True, 0, 0.9),
+                                                  ("std", 1, False, 0, 1.3)])
+def test_chain_per_lane_run_fused_bit_identically(P, lib, kind, D, mass, method, h):
+    """k_lane_hmc (D <= 16: the launch is most of an iteration) keeps a lane's chain for up to 16 iterations of
+    a run and carries U of its position between them.  One run of S iterations == S runs of one, bit for bit."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    N, L, S, seed, chain0, iter0 = 1003, 3, 21, 2, 7, 1
+    rs = np.random.RandomState(D)
+    if kind == "diag":
+        pot = P.GaussianDiag(rs.standard_normal(D), prec=rs.uniform(0.5, 2.0, D), const=0.0)
+    elif kind == "harm":
+        pot = P.Harmonic(rs.uniform(0.5, 2.0, D))
+    elif kind == "ros":
+        pot = P.Rosenbrock(D)
+    else:
+        pot = P.StandardGaussian(1)
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    st = stream_ptr(0)
+    q0 = (1.0 if kind == "ros" else 0.0) + (0.3 if kind == "ros" else 1.0) * rs.standard_normal((D, N))
+
+    def run(s_per_call, record=True):
+        qd = as_device(q0, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
+        for i in range(0, S, s_per_call):
+            lib.call("pbbi_hmc_run", pot.handle, method, qd.data_ptr(), md.data_ptr() if mass else None,
+                     samples[i].data_ptr() if record else None, momenta[i].data_ptr() if record else None,
+                     reject[i].data_ptr() if record else None, ratio[i].data_ptr() if record else None,
+                     N, N, h, L, min(s_per_call, S - i), lib.COMPAT_P_FROM_OLDQ, seed, iter0 + i, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        return to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(ratio), to_numpy(qd)
+
+    one, each = run(S), run(1)
+    for a, b in zip(one, each):
+        assert np.array_equal(a, b)
+    assert 0.02 < one[2].mean() < 0.98
+    assert np.array_equal(run(S, record=False)[4], one[4])
