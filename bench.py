@@ -25,8 +25,8 @@ once the chip has run >= SETTLE iterations in all (its clock needs ~30 ms of thi
 DESIGN.md section 5); the two agree when W >= SETTLE.
 
 At N = 1 the same JSON line also carries, under "other_workloads", the lines of BASELINE configs C3
-(Rosenbrock d=32, 262 144 chains; PBBI_KDK_FMA and reference operation order) and C5 (d=4096 dense,
-fp32, 8 192 chains), measured after the headline (`--no-extras` skips them; `--workload c3|c5|
+(Rosenbrock d=32, 262 144 chains; PBBI_KDK_FMA and reference operation order), C5 (d=4096 dense,
+fp32, 8 192 chains) and of C2 through the class API's default rng="numpy" mode, measured after the headline (`--no-extras` skips them; `--workload c3|c5|
 stream|parity` prints one of them as its own line instead).
 """
 import argparse
@@ -560,7 +560,10 @@ def main():
             extras = {}
             for name, fn in (("c3_kdk_fma", lambda: bench_c3(args, False)),
                              ("c3_exact_order", lambda: bench_c3(args, True)),
-                             ("c5", lambda: bench_c5(args))):
+                             ("c5", lambda: bench_c5(args)),
+                             # the drop-in's default mode (the reference's NumPy stream, bit-exact): 30 iterations
+                             ("c2_class_api_rng_numpy", lambda: bench_parity(argparse.Namespace(
+                                 chains=args.chains, steps=min(args.steps, 30), warmup=3)))):
                 try:
                     extras[name] = fn()
                 except Exception as e:  # the headline line must still print
