@@ -60,25 +60,44 @@ class _HostDrawPipeline:
         self.error = None
         self.thread = None
         self.stop = False
+        self.finished = False
         if self.S == 0:
             return
         self.side = t.cuda.Stream(device=dev(device))
         self.main = t.cuda.current_stream(dev(device))
         td = torch_dtype(np_dtype)
         self.free = queue.Queue()   # slots the consumer has handed back (initially: all of them)
+        # the staging buffers of the previous call with the same shape are kept (pinning 3 x D*N doubles takes
+        # longer than a short run's draws); one shape at a time
+        self.key = (int(D), int(N), str(td), str(dev(device)))
+        cached = _HostDrawPipeline._cache.pop(self.key, [])
+        _HostDrawPipeline._cache.clear()
         self.slots = []
         for _ in range(min(depth, self.S)):
-            s = self.Slot()
-            s.pin_p = t.empty((D, N), dtype=td, pin_memory=True)
-            s.pin_u = t.empty((N,), dtype=td, pin_memory=True)
-            s.p = t.empty((D, N), dtype=td, device=dev(device))
-            s.u = t.empty((N,), dtype=td, device=dev(device))
-            s.uploaded = t.cuda.Event()
+            if cached:
+                s = cached.pop()
+            else:
+                s = self.Slot()
+                s.pin_p = t.empty((D, N), dtype=td, pin_memory=True)
+                s.pin_u = t.empty((N,), dtype=td, pin_memory=True)
+                s.p = t.empty((D, N), dtype=td, device=dev(device))
+                s.u = t.empty((N,), dtype=td, device=dev(device))
+                s.uploaded = t.cuda.Event()
             s.consumed = None
             self.slots.append(s)
             self.free.put(s)
-        self.thread = threading.Thread(target=self._produce, daemon=True)
-        self.thread.start()
+        # One producer thread for the process, not one per call: the host stream's OpenMP team belongs to the
+        # thread that calls it, and a fresh thread would start a fresh team (and first-touch its buffers) in
+        # every getSamples call -- 3 ms per iteration of a 30-iteration run.
+        self.done = threading.Event()
+        self.thread = _producer()
+        self.thread.jobs.put(self._run)
+
+    def _run(self):
+        try:
+            self._produce()
+        finally:
+            self.done.set()
 
     def _produce(self):
         import time
@@ -128,7 +147,38 @@ class _HostDrawPipeline:
         self.stop = True
         if self.thread is not None:
             self.free.put(None)   # wakes a producer that waits for a slot
-            self.thread.join()
+            self.done.wait()
+            # a run that went through keeps its staging buffers for the next call (getSamples synchronises the
+            # device before it returns, so nothing reads them any more)
+            if self.finished and self.error is None:
+                _HostDrawPipeline._cache[self.key] = list(self.slots)
+
+    _cache = {}
+
+class _Producer:
+    """The process's host-draw thread: runs the pipelines' producer loops one after the other."""
+
+    def __init__(self):
+        import queue
+        import threading
+        self.jobs = queue.Queue()
+        self.thread = threading.Thread(target=self._loop, daemon=True, name="pbbi-host-draws")
+        self.thread.start()
+
+    def _loop(self):
+        while True:
+            self.jobs.get()()
+
+
+_producer_singleton = None
+
+
+def _producer():
+    global _producer_singleton
+    if _producer_singleton is None or not _producer_singleton.thread.is_alive():
+        _producer_singleton = _Producer()
+    return _producer_singleton
+
 
 # adaptStepSize's Philox key = seed ^ this (the sampling run keeps `seed`)
 WARMUP_SEED_MASK = 0xA5A55A5ADA7A0001
@@ -343,7 +393,7 @@ class HMC:
                               reject[i].data_ptr(), N, N, h, L, flags, kT_host, stream)
                     pipe.release(slot)
                     q_prev = samples[i]
-                pipe.stop = False  # every iteration was consumed: nothing to cut short
+                pipe.finished = True  # every iteration was launched: the staging buffers may be kept
             finally:
                 pipe.close()
             self.host_rng_ms = pipe.draw_seconds * 1e3 / max(S, 1)
