@@ -83,6 +83,27 @@ def profile_json(pattern, key):
     return None, None
 
 
+def roofline(bound, kernel, peak, unit, t_iter, t_iter_steady, executed, algorithmic, what, **extra):
+    """One roofline block.  `frac` / `achieved` count the work the launch EXECUTES (`executed`, per
+    iteration: what the hardware did, so the fraction is a utilisation and cannot pass 1);
+    `frac_algorithmic` / `achieved_algorithmic` count SURVEY 8d's per-iteration figure (`algorithmic`),
+    which includes work a fused / carried launch no longer does -- it is printed as a fraction only while
+    it stays <= 1 (beyond that it no longer describes a utilisation; the rate is still printed)."""
+    scale = 1e12 if unit == "TFLOP/s" else 1e9
+    ach, ach_s = executed / t_iter / scale, executed / t_iter_steady / scale
+    alg, alg_s = algorithmic / t_iter / scale, algorithmic / t_iter_steady / scale
+    key = "flops" if unit == "TFLOP/s" else "bytes"
+    out = {"bound": bound, "kernel": kernel, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+           "frac_steady": ach_s / peak, "frac_basis": "executed: " + what,
+           "frac_executed": ach / peak,  # (same number; key kept from round 2)
+           "achieved_algorithmic": alg, "frac_algorithmic": alg / peak if alg <= peak else None,
+           "frac_algorithmic_steady": alg_s / peak if alg_s <= peak else None,
+           f"required_{key}_per_iteration": executed, f"algorithmic_{key}_per_iteration": algorithmic,
+           "iteration_ms": t_iter * 1e3, "iteration_ms_steady": t_iter_steady * 1e3}
+    out.update(extra)
+    return out
+
+
 # ------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(Pm, L, seconds_target=4.0):
     """The oracle (CPU restatement of the reference loop; 'port') on a bounded sample of the same
@@ -187,10 +208,34 @@ def bench_c3(args, exact_order):
     fuse = int(os.environ.get("PBBI_FUSE_ITERS", "16"))
     n_launches = -(-K // max(fuse, 1))
     ks, kss = ev * 1e-3 / K, evs * 1e-3 / K
-    bytes_launch = bytes_per_step_chain(d, L) * L * N
-    traffic, src = (None, None)
-    if not exact_order and N == 262144:
-        traffic, src = profile_json("r*_pmc_c3.json", "hbm_bytes_per_launch")  # per iteration
+    bytes_alg = bytes_per_step_chain(d, L) * L * N
+    ipl = K / n_launches
+    # what a fused launch moves per iteration: both sample slabs and the decision bytes are written, the
+    # position is read once per LAUNCH (the chain stays in registers), the momentum is drawn in the kernel
+    bytes_req = (2.0 * d * 8 + 1) * N + d * 8.0 * N / ipl
+    traffic, src = profile_json("r*_pmc_c3_exact.json" if exact_order else "r*_pmc_c3.json", "hbm_bytes_per_launch")
+    instr, _ = profile_json("r*_pmc_c3_exact.json" if exact_order else "r*_pmc_c3.json",
+                            "valu_instructions_per_wave_iteration")
+    if N != 262144:
+        traffic = src = instr = None
+    rl = roofline("hbm", "k_ros2_hmc<unit mass, D=32> (two lanes per chain)", HBM_PEAK_GBS, "GB/s", ks, kss,
+                  bytes_req, bytes_alg,
+                  "q and p sample slabs + decisions written every iteration, q read once per fused launch; "
+                  "frac_algorithmic = SURVEY 8d's 4*D*w + w + 1 bytes per chain and iteration",
+                  traffic=traffic, traffic_source=src, iterations_per_launch=ipl,
+                  launch_ms=ks * 1e3 * ipl, launch_ms_steady=kss * 1e3 * ipl,
+                  note="one k_ros2_hmc launch = iterations_per_launch fused HMC iterations; every figure is per "
+                       "iteration.  The kernel is bound by fp64 vector-instruction ISSUE, not by HBM (see "
+                       "`issue`): the HBM fraction is a proxy")
+    if instr:
+        # one fp64 (or 64-bit integer multiply) instruction occupies its SIMD for ~4.5 cycles with >= 2 waves
+        # resident (tools/ubench/valu_f64_clock.hip); 1024 SIMDs, 2.4 GHz nominal
+        waves = 2 * N / 64
+        floor_s = instr * waves * 4.5 / (1024 * 2.4e9)
+        rl["issue"] = {"valu_instructions_per_wave_iteration": instr, "issue_floor_ms": floor_s * 1e3,
+                       "frac_of_issue_floor": floor_s / ks, "frac_of_issue_floor_steady": floor_s / kss,
+                       "note": "instructions per wave and iteration from the committed --pmc pass x 4.5 cycles "
+                               "per instruction and SIMD at 2.4 GHz"}
     return {
         "metric": "leapfrog-steps*chains/sec; Rosenbrock d=32, ensemble=262144 (config C3)",
         "value": K * L * N / t, "value_steady": K * L * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K,
@@ -199,17 +244,7 @@ def bench_c3(args, exact_order):
                    "integrator_form": "velocity-Verlet, reference operation order (bit-exact)"
                    if exact_order else "kick-drift-kick with FMA (PBBI_KDK_FMA)",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "hbm", "kernel": "k_ros2_hmc<unit mass, D=32> (two lanes per chain)",
-                     "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS,
-                     "frac_steady": bytes_launch / kss / 1e9 / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": src,
-                     "algorithmic_bytes_per_iteration": bytes_launch,
-                     "iteration_ms": ks * 1e3, "iteration_ms_steady": kss * 1e3,
-                     "iterations_per_launch": K / n_launches,
-                     "launch_ms": ks * 1e3 * K / n_launches, "launch_ms_steady": kss * 1e3 * K / n_launches,
-                     "note": "one k_ros2_hmc launch = iterations_per_launch fused HMC iterations; achieved / "
-                             "frac / traffic are per iteration"}}
+        "roofline": rl}
 
 
 def bench_stream(args):
@@ -249,9 +284,13 @@ def bench_stream(args):
                       stream)
             S, it0 = S - s, it0 + s
     (t, ev), (ts, evs) = timed_runs(run, K, W, max(W + K, SETTLE))
-    ks = ev * 1e-3 / K
-    bytes_launch = bytes_per_step_chain(d, L, w) * L * N
-    design = (6 * L + 12) * w * d * N  # per launch: 6 accesses per element-step + init/energy/output sweeps
+    ks, kss = ev * 1e-3 / K, evs * 1e-3 / K
+    bytes_alg = bytes_per_step_chain(d, L, w) * L * N
+    # the least any kernel must move per iteration of a run with in-kernel draws: both sample slabs and the
+    # decision bytes written (fused kernels move exactly this plus one position read per launch; unfused
+    # ones also read the position every iteration)
+    bytes_req = (2.0 * d * w + 1) * N
+    design = (6 * L + 12) * w * d * N  # workspace kernels: 6 accesses per element-step + init/energy/output sweeps
     return {
         "metric": f"leapfrog-steps*chains/sec; {args.potential} d={d}, ensemble={N}, {args.dtype}",
         "value": K * L * N / t, "value_steady": K * L * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K,
@@ -260,10 +299,11 @@ def bench_stream(args):
                    "integrator_form": "reference operation order" if args.exact_order
                    else "PBBI_KDK_FMA where a kernel honours it",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "hbm", "kernel": "k_lane_hmc / k_ros2_hmc / k_sepn / k_rosg / k_stream_hmc",
-                     "achieved": bytes_launch / ks / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_launch / ks / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "design_traffic_GBs": design / ks / 1e9, "launch_ms": ks * 1e3}}
+        "roofline": roofline("hbm", "k_lane_hmc / k_ros2_hmc / k_sepn / k_rosg / k_stream_hmc", HBM_PEAK_GBS,
+                             "GB/s", ks, kss, bytes_req, bytes_alg,
+                             "the q and p sample slabs and the decision bytes an iteration must write (lower "
+                             "bound of any kernel's traffic); frac_algorithmic = SURVEY 8d's 4*D*w + w + 1",
+                             traffic=None, design_traffic_GBs=design / ks / 1e9, launch_ms=ks * 1e3)}
 
 
 def bench_c5(args):
@@ -291,28 +331,33 @@ def bench_c5(args):
                       momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, s, 1, 7, it0, 0, 1.0, stream)
             S, it0 = S - s, it0 + s
     (t, ev), (ts, evs) = timed_runs(run, K, W, W + K)  # 25 ms iterations: settled after two
-    it_s = ev * 1e-3 / K
+    it_s, it_ss = ev * 1e-3 / K, evs * 1e-3 / K
     flops_it = 2.0 * d * d * (L + 1) * N
     # inside pbbi_hmc_run the first GEMM of an iteration is replaced by an elementwise pass over the gradient
     # the previous iteration kept: L GEMMs are executed where SURVEY 8d's figure counts L + 1
     carried = os.environ.get("PBBI_NO_CARRY") is None
     flops_exec = 2.0 * d * d * (L if carried else L + 1) * N
+    traffic = src = None
+    if N == 8192:
+        rd, src = profile_json("r*_pmc_c5.json", "fetch_bytes_per_launch_x2")
+        wr, _ = profile_json("r*_pmc_c5.json", "write_bytes_per_launch")
+        if rd is not None and wr is not None:
+            traffic = (rd + wr) * (L if carried else L + 1)  # counters are per GEMM launch
     return {
         "metric": "leapfrog-steps*chains/sec; d=4096 dense Gaussian fp32, ensemble=8192 (config C5)",
         "value": K * L * N / t, "value_steady": K * L * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K,
         "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C5: d=4096 dense precision, {N} chains, fp32, L=10, h=0.05",
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
-        "roofline": {"bound": "mfma", "kernel": "k_big_gemm_wide<256x128x16, KDK> x L per iteration (+ k_big_first_kick on the carried gradient)",
-                     "achieved": flops_it / it_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops_it / it_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "achieved_executed": flops_exec / it_s / 1e12,
-                     "frac_executed": flops_exec / it_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                     "note": ("frac = SURVEY 8d's algorithmic flops (L + 1 gradient GEMMs per iteration) / time / "
-                              "peak; frac_executed counts the L GEMMs performed (gradient carried between "
-                              "iterations, bit-identical samples)") if carried else None,
-                     "algorithmic_flops_per_iteration": flops_it, "executed_flops_per_iteration": flops_exec,
-                     "iteration_ms": it_s * 1e3}}
+        "roofline": roofline("mfma", "k_big_gemm_wide<256x128x16, KDK> x L per iteration (+ k_big_first_kick on "
+                             "the carried gradient)", FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", it_s, it_ss, flops_exec,
+                             flops_it,
+                             "the L gradient GEMMs an iteration performs (the first of SURVEY 8d's L + 1 is "
+                             "replaced by a pass over the gradient the previous iteration kept; bit-identical "
+                             "samples); frac_algorithmic counts L + 1" if carried else "L + 1 gradient GEMMs",
+                             traffic=traffic, traffic_source=src,
+                             traffic_note="HBM bytes per iteration = (FETCH_SIZE x 2 KiB + WRITE_SIZE x 1 KiB) of "
+                                          "one k_big_gemm_wide launch x GEMMs per iteration (separate --pmc passes)")}
 
 
 def bench_parity(args):
@@ -417,10 +462,15 @@ def bench_c2(args, rank, world, local_rank):
     # iteration are EXECUTED where SURVEY 8d's algorithmic figure counts L + 1.  Both rates are reported.
     carried = os.environ.get("PBBI_NO_CARRY") is None
     fuse_max = max(1, int(os.environ.get("PBBI_DENSE_FUSE", "64"))) if carried else 1
-    # a timed run = one pbbi_hmc_run of K iterations: the first on its own launch, the rest in equal fused launches
-    fuse = (K - 1) / (-(-(K - 1) // fuse_max)) if (fuse_max > 1 and K > 1) else 1
-    flops_exec = (2.0 * D * D * (L if carried else L + 1) + 11.0 * D * L + 8.0 * D) * N
-    bytes_exec = bytes_launch + (2.0 * D * 8 * N if carried else 0.0)  # g read + g(q_new) written
+    # a timed run = one pbbi_hmc_run of K iterations in equal fused launches (the first iteration of the run
+    # forms g(q_0) inside its launch: L + 1 mat-vecs once per run, counted below)
+    n_launch = -(-K // fuse_max) if (fuse_max > 1 and K > 1) else K
+    fuse = K / n_launch
+    matvecs = (L + 1.0 / K) if carried else L + 1  # per iteration, averaged over the timed run
+    flops_exec = (2.0 * D * D * matvecs + 11.0 * D * L + 8.0 * D) * N
+    # both sample slabs + decisions written; the carried gradient read and g(q_new) written; the position is
+    # read once per launch (the momentum is drawn in the kernel: SURVEY 8d's figure counts a read for it)
+    bytes_exec = ((2.0 * D * 8 + 1) * N + D * 8.0 * N / fuse + 2.0 * D * 8 * N) if carried else bytes_launch
     out = {
         "metric": "leapfrog-steps*chains/sec (node); d=128 Gaussian, ensemble=65536",
         "value": K * L * total_chains / t,
@@ -442,27 +492,17 @@ def bench_c2(args, rank, world, local_rank):
                    "chains_per_gpu": N, "total_chains": total_chains, "D": D, "L": L,
                    "stepSize": STEP, "parallelism": f"ensemble-sharded x{world}",
                    "accept_rate": accept},
-        "roofline": {
-            "bound": "mfma",
-            "kernel": "k_dense_hmc<8, full, hmc, zero-mean" + (", carried gradient, fused iterations>" if carried else ">"),
-            # per ITERATION (one step of this bench); a launch covers iterations_per_launch of them
-            "achieved": flops_launch / kernel_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": flops_launch / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            "frac_steady": flops_launch / kernel_ss / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            "achieved_executed": flops_exec / kernel_s / 1e12,
-            "frac_executed": flops_exec / kernel_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            "note": ("frac = SURVEY 8d's algorithmic flops (L + 1 gradient mat-vecs per iteration) / time / peak; "
-                     "frac_executed counts the L mat-vecs the kernel performs (the gradient at the chain's "
-                     "position is carried between iterations, bit-identical samples)") if carried else None,
-            "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_flops_per_iteration": flops_launch, "algorithmic_flops_per_launch": flops_launch * fuse,
-            "algorithmic_bytes_per_iteration": bytes_launch, "algorithmic_bytes_per_launch": bytes_launch * fuse,
-            "executed_flops_per_iteration": flops_exec, "executed_bytes_per_iteration": bytes_exec,
-            "iteration_ms": kernel_s * 1e3, "iterations_per_launch": fuse,
-            "launch_ms": kernel_s * 1e3 * fuse, "launch_ms_steady": kernel_ss * 1e3 * fuse,
-            "hbm_algorithmic_GBs": bytes_launch / kernel_s / 1e9,
-            "hbm_frac_of_8TBs": bytes_launch / kernel_s / 1e9 / HBM_PEAK_GBS,
-        },
+        "roofline": roofline(
+            "mfma", "k_dense_hmc<8, full, hmc, zero-mean" + (", carried gradient, fused iterations>" if carried else ">"),
+            FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", kernel_s, kernel_ss, flops_exec, flops_launch,
+            ("the L gradient mat-vecs + updates + energies an iteration performs (the gradient at the chain's "
+             "position is carried between iterations, bit-identical samples); frac_algorithmic = SURVEY 8d's count "
+             "with L + 1 mat-vecs") if carried else "L + 1 gradient mat-vecs + updates + energies (SURVEY 8d)",
+            traffic=traffic, traffic_source=traffic_src,
+            algorithmic_bytes_per_iteration=bytes_launch, required_bytes_per_iteration=bytes_exec,
+            iterations_per_launch=fuse, launch_ms=kernel_s * 1e3 * fuse, launch_ms_steady=kernel_ss * 1e3 * fuse,
+            hbm_required_GBs=bytes_exec / kernel_s / 1e9,
+            hbm_frac_of_8TBs=bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS),
     }
     if allgather_ms is not None:
         out["allgather_ms"] = allgather_ms

@@ -117,7 +117,9 @@ struct DensePrm {
     uint8_t* carry_sel;         // [N]: which of the two slabs holds g at the chain's current position
     uint32_t carry_slab_bytes;  // D*N*8
     // several iterations of a run in one launch (FUSE, see k_dense_hmc; IterArgs::fuse_*)
-    int fuse_S, fuse_wrap2;
+    // fuse_first: iteration 0 of this launch is the FIRST of the run -- it forms g(q_0) itself and stores
+    // it as slab 0 of the carried gradient (what a CARRY = 1 launch of its own used to do)
+    int fuse_S, fuse_wrap2, fuse_first;
     int64_t fuse_slab0, fuse_slab;
     double* fuse_q_base;
 };
@@ -535,7 +537,7 @@ template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, b
           bool FUSE = false>
 __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     static_assert(CARRY == 0 || (MODE == 0 && METHOD == PBBI_LEAPFROG && !DYN), "carry: plain Leapfrog iterations");
-    static_assert(!FUSE || CARRY == 2, "a fused launch continues a run whose first iteration stored g(q_0)");
+    static_assert(!FUSE || CARRY == 2, "a fused launch reads the carried gradient (its first iteration may form it)");
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
     constexpr int NPASS = NT >= 4 ? 2 : 1;  // row passes per mat-vec
@@ -609,6 +611,34 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     // decision rows kf.  Waves that share a SIMD drift apart, so one's draw and stores run under the other's
     // MFMAs; P is staged once per launch and q is never re-read while the chain keeps accepting.
     const int nfuse = FUSE ? prm.fuse_S : 1;
+    if constexpr (FUSE) {
+        // The launch starts the run (fuse_first): no carried gradient exists yet.  g(q_0) is formed here, once,
+        // and stored as slab 0 -- what a CARRY = 1 launch did -- so that the loop below has ONE shape for every
+        // iteration (a branch inside it cost 33 spilled registers): iteration 0 reads back what this wave just
+        // wrote (same wave, same addresses: program order).
+        if (prm.fuse_first) {
+            const uint32_t vg0 = (uint32_t)g * ld_g + 8u * (uint32_t)cc;
+            v4f64 acc0[NTP];
+            matvec_pass<NT, NTP, 0, false, ZMEAN>(fragL, muG, q, q, acc0, h);
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store_elem<FULL>(gbuf, vg0, s4g, 4 * t + r, g, D, acc0[t][r]);
+            }
+            if constexpr (NPASS == 2) {
+                matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, q, acc0, h);
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            store_elem<FULL>(gbuf, vg0, s4g, 4 * (NTP + t) + r, g, D, acc0[t][r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma nounroll
     for (int kf = 0; kf < nfuse; ++kf) {
     const uint64_t iter_k = prm.iter + (uint64_t)kf;
@@ -1159,8 +1189,10 @@ int dense_hmc_iter(const IterArgs& a) {
         prm.carry_slab_bytes = (uint32_t)((uint64_t)a.pot->D * (uint64_t)a.N * 8u);
     }
     if (a.fuse_S > 1) {
-        if (carry != 2 || a.ldn_in != a.ldn_out || !a.rng)
-            return pbbi_fail(PBBI_ERR_INVALID, "fused dense iterations continue a carried run (internal)");
+        if (carry == 0 || a.ldn_in != a.ldn_out || !a.rng)
+            return pbbi_fail(PBBI_ERR_INVALID, "fused dense iterations belong to a carried run (internal)");
+        prm.fuse_first = (carry == 1);  // the launch starts the run: its iteration 0 forms g(q_0)
+        carry = 2;
         prm.fuse_S = a.fuse_S;
         prm.fuse_wrap2 = a.fuse_wrap2;
         prm.fuse_slab0 = a.fuse_slab0;
@@ -1170,15 +1202,17 @@ int dense_hmc_iter(const IterArgs& a) {
     return launch_traj(a.pot, a.method, prm, a.N, a.stream, carry);
 }
 
-// Iterations of a run that ONE launch may cover (k_dense_hmc FUSE): the iterations after the first of a
-// run that carries its gradient, in-kernel draws.  PBBI_DENSE_FUSE=n overrides the chunk (1 = off).
+// Iterations of a run that ONE launch may cover (k_dense_hmc FUSE): a run that carries its gradient, in-kernel
+// draws, the state the launch starts from stored with the slabs' stride (a run's first iteration reads the
+// caller's q_state: ldn == N, else that iteration gets a launch of its own).  PBBI_DENSE_FUSE=n overrides the
+// chunk (1 = off).
 int dense_fused_iterations(const IterArgs& a) {
     static const int chunk = [] {
         const char* e = getenv("PBBI_DENSE_FUSE");
         const int v = e ? atoi(e) : 64;
         return v < 1 ? 1 : v;
     }();
-    if (a.carry != 2 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a) ||
+    if (a.carry == 0 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a) ||
         a.pot->D != a.pot->DP)  // (the padded-D instantiations of the fused form spill: not built)
         return 1;
     return chunk;

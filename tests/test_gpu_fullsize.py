@@ -115,32 +115,44 @@ def c2_precision(D):
     return 0.5 * (Pm + Pm.T)
 
 
-@pytest.mark.parametrize("ragged", [0, 5])
-def test_c2_full_size_hmc_run_vs_oracle(P, lib, ragged):
-    """bench.py's default workload: D=128, 65 536 chains, L=10, h=0.1, seed 42, compat flag."""
-    D, N, L, h, S, seed = 128, 65536 - ragged, 10, 0.1, 3, 42
+@pytest.mark.parametrize("S,ragged", [(3, 0), (3, 5), (20, 0), (20, 5), (100, 0), (100, 5)])
+def test_c2_full_size_hmc_run_vs_oracle(P, lib, S, ragged):
+    """bench.py's default workload: D=128, 65 536 chains, L=10, h=0.1, seed 42, compat flag -- for the
+    iteration counts bench.py times: S = 20 is the driver's `--steps 20` (ONE fused launch of k_dense_hmc: its
+    first iteration forms g(q_0), the other 19 read the carried gradient), S = 100 the default (two launches of
+    50).  Every iteration of the run is replayed for 16 groups of 16 chains, so the slab index and the
+    carried-gradient selector of a long fused launch are checked at the size and length they are timed at;
+    chains must both accept and reject INSIDE the fused launches (the selector flips and stays).
+    Reference: src/HMC.py:154-179."""
+    D, N, L, h, seed = 128, 65536 - ragged, 10, 0.1, 42
     Pm = c2_precision(D)
     pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
     samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, lib.COMPAT_P_FROM_OLDQ, seed,
                                                 1.0, 0.0)
-    worst = [0.0]
+    worst, rej_later = [0.0], [0]
 
     def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
         assert np.array_equal(grej, rej), f"group {g} iteration {i}"
         worst[0] = max(worst[0], scaled_err(gq, q), scaled_err(gp, p))
+        if i >= 1:
+            rej_later[0] += int(rej.sum())
     n_rej, n_tot = replay_groups(lib, op, chain_groups(N, 16, 128, 1), samples, momenta, reject, qf, D, S,
                                  h, L, seed, 1.0, 0.0, True, np.float64, check)
     assert worst[0] <= 1e-11, worst[0]
     assert n_tot == 16 * GROUP * S
+    if S >= 20:  # replayed chains rejected (selector stays) and accepted (selector flips) after iteration 0
+        assert 0 < rej_later[0] < 16 * GROUP * (S - 1) // 4, rej_later[0]
     # the whole ensemble's accept rate is what bench.py reports as config.accept_rate
     assert 0.5 < 1.0 - float(reject.float().mean()) <= 1.0
 
 
-@pytest.mark.parametrize("kdk,ragged", [(True, 0), (False, 0), (True, 5), (False, 5)])
-def test_c3_full_size_hmc_run_vs_oracle(P, lib, kdk, ragged):
+@pytest.mark.parametrize("kdk,ragged,S", [(True, 0, 3), (False, 0, 3), (True, 5, 3), (False, 5, 3),
+                                          (True, 0, 20), (False, 0, 20), (True, 5, 20), (False, 5, 20)])
+def test_c3_full_size_hmc_run_vs_oracle(P, lib, kdk, ragged, S):
     """bench.py --workload c3 [--exact-order]: Rosenbrock D=32, 262 144 chains, h=0.01, L=10,
-    q0 = 1 + 0.1 z, seed 7."""
-    D, N, L, h, S, seed = 32, 262144 - ragged, 10, 0.01, 3, 7
+    q0 = 1 + 0.1 z, seed 7.  S = 20 is the driver's `--steps 20`: two k_ros2_hmc launches of 10 fused
+    iterations (the chain and U of its position stay in registers between them)."""
+    D, N, L, h, seed = 32, 262144 - ragged, 10, 0.01, 7
     pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
     flags = lib.COMPAT_P_FROM_OLDQ | (lib.KDK_FMA if kdk else 0)
     samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, flags, seed, 0.1, 1.0)
@@ -161,7 +173,7 @@ def test_c3_full_size_hmc_run_vs_oracle(P, lib, kdk, ragged):
 def test_c5_full_size_hmc_run_vs_oracle(P, lib, ragged):
     """bench.py --workload c5: D=4096 dense precision, 8 192 chains, fp32, h=0.05, L=10, seed 7.
     fp32 kernel against the fp64 oracle restarted from the kernel's own previous state."""
-    D, N, L, h, S, seed = 4096, 8192 - ragged, 10, 0.05, 2, 7
+    D, N, L, h, S, seed = 4096, 8192 - ragged, 10, 0.05, 3, 7  # iterations 1, 2 start from carried gradients
     Pm = c2_precision(D)
     pot = P.GaussianDense(None, precision=Pm, const=0.0, dtype="float32")
     op = orc.pot_gauss_dense(np.zeros(D), Pm)
