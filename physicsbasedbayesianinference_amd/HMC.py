@@ -34,6 +34,7 @@ from scipy.constants import Boltzmann as boltzmannConst
 from . import _hoststream, _lib
 from ._device import as_device, empty, stream_ptr, synchronize, to_numpy
 from .integrator import Leapfrog, StormerVerlet, mass_or_none, resolve_potential
+from .potential import Potential
 
 __all__ = ["HMC"]
 
@@ -203,24 +204,38 @@ class HMC:
         self.seed = int(seed)
         self.verbose = verbose
 
-        # potential: given descriptor, else the descriptor behind `density` (-log density)
+        # potential: given descriptor, else the descriptor behind `density` (-log density); plain Python
+        # callables (the reference's lambdas, :52-60) are traced into one (trace.py)
+        D = ensemble.numDimensions
+        traced_gradient = gradient is not None and callable(gradient) and \
+            not isinstance(getattr(gradient, "__self__", gradient), Potential)
         if potential:
-            self._pot = resolve_potential(potential, "potential")
+            if traced_gradient and not isinstance(getattr(potential, "__self__", potential), Potential):
+                # potential AND gradient as callables: one descriptor from both (a hand-written gradient
+                # is used as written; grad(potential) means "differentiate the trace")
+                self._pot = resolve_potential(gradient, "gradient", D, potential=potential)
+            else:
+                self._pot = resolve_potential(potential, "potential", D)
+                if traced_gradient:
+                    raise ValueError("gradient= is a Python callable but potential= is a descriptor, which "
+                                     "brings its own gradient")
             self.potential = potential
         else:
-            self._pot = resolve_potential(density, "density")
+            self._pot = resolve_potential(density, "density", D)
             self.potential = self.potentialFunc
         if gradient:
-            if resolve_potential(gradient, "gradient") is not self._pot:
+            if not traced_gradient and resolve_potential(gradient, "gradient") is not self._pot:
                 raise ValueError("gradient= must belong to the same descriptor as potential=")
             self.gradient = gradient
         else:
             self.gradient = self._pot.gradient  # stands in for jax.grad(self.potential) (:60)
+        # the integrator gets the DESCRIPTOR's gradient: whatever `gradient` was, it is part of self._pot now
+        integ_gradient = self._pot.gradient
 
         if method == "Leapfrog":
-            self.integrator = Leapfrog(ensemble, stepSize, simulTime, self.gradient)
+            self.integrator = Leapfrog(ensemble, stepSize, simulTime, integ_gradient)
         elif method == "Stormer-Verlet":
-            self.integrator = StormerVerlet(ensemble, stepSize, simulTime, self.gradient)
+            self.integrator = StormerVerlet(ensemble, stepSize, simulTime, integ_gradient)
         else:
             raise ValueError("Invalid integration method selected.")
         self.method = method
@@ -231,7 +246,10 @@ class HMC:
 
     # ------------------------------------------------------------------ helpers
     def potentialFunc(self, q):
-        """U(q) = -log(density(q))  (src/HMC.py:75-84)."""
+        """U(q) = -log(density(q))  (src/HMC.py:75-84); for a traced density: the descriptor's U(q),
+        evaluated by the HIP kernel."""
+        if not isinstance(getattr(self.density, "__self__", self.density), Potential):
+            return self._pot(q)
         return -np.log(self.density(q))
 
     def _upload_state(self, *arrays):

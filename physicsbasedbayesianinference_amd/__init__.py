@@ -16,8 +16,11 @@ from .potential import (GaussianDense, GaussianDiag, Harmonic, Potential, Rosenb
 from .integrator import Integrator, Leapfrog, StormerVerlet
 from .HMC import HMC
 from .custom import CustomPotential
+from . import trace
+from .trace import grad, trace_potential
 
 __all__ = ["Ensemble", "HMC", "Integrator", "Leapfrog", "StormerVerlet", "Potential",
            "Harmonic", "GaussianDiag", "StandardGaussian", "GaussianDense", "Rosenbrock",
-           "harmonicPotentialND", "linear_regression_posterior", "CustomPotential"]
+           "harmonicPotentialND", "linear_regression_posterior", "CustomPotential", "trace", "grad",
+           "trace_potential"]
 __version__ = "0.1.0"

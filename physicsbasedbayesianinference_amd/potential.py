@@ -224,7 +224,11 @@ _HARMONIC_CACHE = {}
 
 def harmonicPotentialND(q, springConsts):
     """Drop-in for src/potential.py:18-27: 0.5 * dot(springConsts, q**2) for q of shape
-    (D,) or (D, N), evaluated by the HIP kernel."""
+    (D,) or (D, N), evaluated by the HIP kernel.  On a TRACED q (a lambda around this function handed to
+    HMC / Integrator / grad, src/tests/test_integrator_harmonic.py:23-24) it records the same expression."""
+    from . import trace
+    if trace.is_symbolic(q):
+        return 0.5 * trace.dot(np.asarray(springConsts, dtype=np.float64), q ** 2)
     k = np.ascontiguousarray(springConsts, dtype=np.float64).ravel()
     key = (k.tobytes(), default_device())
     pot = _HARMONIC_CACHE.get(key)

@@ -2070,3 +2070,180 @@ def test_rccl_collectives_run_on_hardware_single_rank():
     if "RCCL-INIT-FAILED" in out:
         pytest.skip("RCCL could not initialise on this box: " + out[-300:])
     assert r.returncode == 0 and "RCCL-OK" in out, out[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------
+# Python callables as potentials (trace.py): the reference's lambdas (src/HMC.py:52-60,
+# src/tests/test_integrator_harmonic.py:22-24, src/tests/test_HMC.py:27-33,48-49,124-125) traced into
+# descriptors / generated kernels -- no C++ string, no CPU path.  Golden fixtures through them.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["descriptor", "source"])
+@pytest.mark.parametrize("name,method", [("G1_leapfrog_harmonic", "Leapfrog"),
+                                         ("G2_stormerverlet_harmonic", "Stormer-Verlet")])
+def test_traced_harmonic_lambda_reproduces_the_integrator_fixtures(P, name, method, route):
+    """harmonicPotential = lambda q: harmonicPotentialND(q, springConsts); harmonicGradient = grad(...)
+    (src/tests/test_integrator_harmonic.py:22-24), handed to Leapfrog / StormerVerlet like the reference
+    does.  route "descriptor": the trace is recognised as Harmonic(k) (bit-exact with the oracle);
+    "source": the same trace pushed through the generated-source kernels."""
+    from physicsbasedbayesianinference_amd.trace import grad, trace_potential
+    g = load_golden(name)
+    springConsts = g["springConsts"]
+    harmonicPotential = lambda q: P.harmonicPotentialND(q, springConsts)   # noqa: E731
+    harmonicGradient = grad(harmonicPotential)
+    cls = P.Leapfrog if method == "Leapfrog" else P.StormerVerlet
+    for s in ("_h0.1", "_h0.01"):
+        D, N = g["q0" + s].shape
+        ens = P.Ensemble(D, N)
+        ens.mass = g["mass" + s].copy()
+        ens.q[...] = g["q0" + s]
+        ens.p[...] = g["p0" + s]
+        gradient = harmonicGradient if route == "descriptor" else \
+            trace_potential(harmonicPotential, D=D, prefer="source")
+        integ = cls(ens, float(g["stepSize" + s]), float(g["finalTime" + s]), gradient)
+        assert integ.potential.kind == ("harmonic" if route == "descriptor" else "custom")
+        q, p = integ.integrate()
+        assert q is ens.q and p is ens.p
+        assert scaled_err(q, g["q" + s]) <= RTOL_GOLDEN and scaled_err(p, g["p" + s]) <= RTOL_GOLDEN
+        assert scaled_err(integ.v, g["v" + s]) <= RTOL_GOLDEN
+        if route == "descriptor":
+            qo, po = np.ascontiguousarray(g["q0" + s]), np.ascontiguousarray(g["p0" + s])
+            orc.integrate(orc.pot_harmonic(springConsts), method, qo, po, g["mass" + s],
+                          float(g["stepSize" + s]), int(g["numSteps" + s]))
+            assert np.array_equal(q, qo) and np.array_equal(p, po)
+    # grad(f) on numbers: the traced descriptor's gradient kernel
+    assert np.array_equal(harmonicGradient(np.array([3.0, 4.0])), springConsts * np.array([3.0, 4.0]))
+
+
+@pytest.mark.parametrize("route", ["descriptor", "source"])
+@pytest.mark.parametrize("name", ["G4_getsamples_dense_d8", "G11_getsamples_test2", "G4b_getsamples_dense_mean_d16"])
+def test_traced_gaussian_lambda_reproduces_getsamples_fixtures(P, name, route):
+    """potential = lambda q: <closed-form -logpdf on the traceable namespace> through HMC.getSamples on the
+    reference's seed: the fixture's samples, momenta and reject masks.  "descriptor": the quadratic form is
+    recognised (GaussianDense: MFMA kernel); "source": generated-source kernels."""
+    from physicsbasedbayesianinference_amd import trace as jnp
+    g = load_golden(name)
+    D, N, S = int(g["D"]), int(g["N"]), int(g["S"])
+    mean, Pm, const = g["mean"], g["precision"], float(g["const"])
+    potentialFunc = lambda q: 0.5 * jnp.dot(q - mean, jnp.dot(Pm, q - mean)) + const   # noqa: E731
+    potential = potentialFunc if route == "descriptor" else jnp.trace_potential(potentialFunc, D=D, prefer="source")
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(D, N)
+    ens.mass = g["mass"].copy()
+    hmc = P.HMC(ens, float(g["simulTime"]), float(g["stepSize"]), None, potential=potential,
+                method=str(g["method"]), verbose=False)
+    assert hmc._pot.kind == ("gauss_dense" if route == "descriptor" else "custom")
+    samples, momenta = hmc.getSamples(S, float(g["temperature"]), float(g["qStd"]))
+    assert np.array_equal(hmc.reject_masks, g["reject_mask"])
+    assert scaled_err(samples, g["samples"]) <= RTOL_DENSE and scaled_err(momenta, g["momenta"]) <= RTOL_DENSE
+
+
+def test_traced_multivariate_normal_and_density_only(P):
+    """src/tests/test_HMC.py:124-130 as written (densityFunc / potentialFunc on multivariate_normal, T = 300 K)
+    against fixture G11 (recorded from the reference with the same mean and covariance), and the density-only
+    construction of src/tests/test_HMC.py:27-33 against fixture G3 (config C1)."""
+    from physicsbasedbayesianinference_amd import trace as jnp
+    from physicsbasedbayesianinference_amd.trace import multivariate_normal
+    g = load_golden("G11_getsamples_test2")
+    mean = jnp.ones(2) * 5
+    cov = jnp.array([[4, -3], [-3, 4]])
+    densityFunc = lambda q: multivariate_normal.pdf(q, mean, cov=cov)          # noqa: E731
+    potentialFunc = lambda q: -multivariate_normal.logpdf(q, mean, cov=cov)    # noqa: E731
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(2, int(g["N"]))
+    hmc = P.HMC(ens, float(g["simulTime"]), float(g["stepSize"]), densityFunc, potential=potentialFunc, verbose=False)
+    samples, momenta = hmc.getSamples(int(g["S"]), float(g["temperature"]), float(g["qStd"]))
+    assert hmc._pot.kind == "gauss_dense"
+    assert np.array_equal(hmc.reject_masks, g["reject_mask"])
+    assert scaled_err(samples, g["samples"]) <= RTOL_DENSE and scaled_err(momenta, g["momenta"]) <= RTOL_DENSE
+    # density only: potential = -log(density)  (src/HMC.py:75-84)
+    g = load_golden("G3_getsamples_c1")
+    density = lambda x: jnp.exp(-0.50 * jnp.linalg.norm(x) ** 2) / jnp.sqrt(2 * jnp.pi)   # noqa: E731
+    np.random.seed(int(g["seed"]))
+    ens = P.Ensemble(1, int(g["N"]))
+    hmc = P.HMC(ens, float(g["simulTime"]), float(g["stepSize"]), density, verbose=False)
+    samples, momenta = hmc.getSamples(int(g["S"]), float(g["temperature"]), float(g["qStd"]))
+    assert np.array_equal(hmc.reject_masks, g["reject_mask"])
+    assert scaled_err(samples, g["samples"]) <= RTOL_GOLDEN and scaled_err(momenta, g["momenta"]) <= RTOL_GOLDEN
+    assert abs(hmc.potential(np.array([0.3])) - (0.5 * 0.09 + 0.5 * np.log(2 * np.pi))) < 1e-15
+
+
+def test_traced_nonquadratic_callable_vs_oracle(P, lib):
+    """A callable with no closed-form descriptor (logistic regression written on the namespace): generated
+    source + symbolic gradient in the plugin kernels against the oracle running the SAME generated source on
+    the host -- decisions equal, states within 1e-10 -- and against the hand-written C++ of
+    custom.LOGISTIC_REGRESSION_SOURCE (values within 1e-12)."""
+    from physicsbasedbayesianinference_amd import trace as jnp
+    from physicsbasedbayesianinference_amd.custom import complete_source, logistic_regression_posterior
+    rs = np.random.RandomState(4)
+    M, D, N = 24, 5, 300
+    X = rs.standard_normal((M, D))
+    y = (rs.uniform(size=M) < 0.5).astype(np.float64)
+
+    def softplus(z):
+        return jnp.maximum(z, 0.0) + jnp.log1p(jnp.exp(-jnp.abs(z)))
+
+    fn = lambda w: jnp.sum(softplus(X @ w) - y * (X @ w)) + 0.5 * jnp.dot(w, w)   # noqa: E731
+    pot = jnp.trace_potential(fn, D=D)
+    assert pot.kind == "custom"
+    q = rs.standard_normal((D, N))
+    U, gr = pot.value_and_gradient(q)
+    hand = logistic_regression_posterior(X, y, 1.0)
+    Uh, gh = hand.value_and_gradient(q)
+    assert scaled_err(U, Uh) <= 1e-12 and scaled_err(gr, gh) <= 1e-12
+    op = orc.pot_custom(complete_source(pot.traced_source), D)
+    h, L = 0.2, 6
+    for it in range(3):
+        p, u = rs.standard_normal((D, N)), rs.uniform(size=N)
+        qo, po, ratio, rej = gpu_hmc_iter(lib, pot, "Leapfrog", q, p, u, None, h, L)
+        q_or, p_or = q.copy(), p.copy()
+        _, rej_or = orc.hmc_iter(op, "Leapfrog", q_or, p_or, u, None, h, L)
+        assert np.array_equal(rej, rej_or)
+        assert scaled_err(qo, q_or) <= 1e-10 and scaled_err(po, p_or) <= 1e-10
+        q = qo
+
+
+def test_untraceable_callable_raises_typeerror_in_the_class_api(P):
+    import math
+    ens = P.Ensemble(2, 4)
+    with pytest.raises(TypeError):
+        P.HMC(ens, 1.0, 0.1, None, potential=lambda q: math.exp(q[0]), verbose=False)
+    with pytest.raises(TypeError):
+        P.Leapfrog(ens, 0.1, 1.0, lambda q: np.tanh(q))
+
+
+def test_reference_script_runs_through_dropin_with_its_own_imports(tmp_path):
+    """The reference's harmonic test set-up (src/tests/test_integrator_harmonic.py:13-24,41-81) with ITS import
+    lines -- `from ensemble import Ensemble`, `from integrator import Leapfrog`, `from potential import
+    harmonicPotentialND`, `from jax import grad` -- resolved by dropin/ (dropin/jax is the traceable namespace):
+    fixture G1 to its tolerance."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = load_golden("G1_leapfrog_harmonic")
+    inp, outp = tmp_path / "in.npz", tmp_path / "out.npz"
+    np.savez(inp, q0=g["q0_h0.1"], p0=g["p0_h0.1"], mass=g["mass_h0.1"], k=g["springConsts"],
+             h=g["stepSize_h0.1"], T=g["finalTime_h0.1"])
+    script = f"""
+import sys
+sys.path[:0] = [{root!r}, {os.path.join(root, "dropin")!r}]
+from ensemble import Ensemble
+from integrator import Leapfrog, StormerVerlet
+from potential import harmonicPotentialND
+from jax import grad
+import numpy as np
+z = np.load({str(inp)!r})
+springConsts = z["k"]
+harmonicPotential = lambda q: harmonicPotentialND(q, springConsts)
+harmonicGradient = grad(harmonicPotential)
+ensemble1 = Ensemble(2, z["q0"].shape[1])
+ensemble1.mass = z["mass"].copy()
+ensemble1.q[...] = z["q0"]
+ensemble1.p[...] = z["p0"]
+sol_q_p = Leapfrog(ensemble1, float(z["h"]), float(z["T"]), harmonicGradient)
+q_num, p_num = sol_q_p.integrate()
+np.savez({str(outp)!r}, q=q_num, p=p_num)
+"""
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = np.load(outp)
+    assert scaled_err(out["q"], g["q_h0.1"]) <= RTOL_GOLDEN and scaled_err(out["p"], g["p_h0.1"]) <= RTOL_GOLDEN

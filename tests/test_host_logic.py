@@ -120,7 +120,7 @@ def test_numsteps_and_constructor_logic():
     with pytest.raises(NotImplementedError):
         Leapfrog(ens, 0.1, 1.0, None)            # N-body mode is out of scope
     with pytest.raises(TypeError, match="no CPU fallback"):
-        Leapfrog(ens, 0.1, 1.0, lambda q: q)     # arbitrary callables are rejected
+        Leapfrog(ens, 0.1, 1.0, lambda q: np.tanh(q))   # callables that cannot be traced are rejected
     with pytest.raises(ValueError, match="Invalid integration method selected."):
         HMC(ens, 1.0, 0.1, None, potential=pot, method="RK4")
     h = HMC(ens, 0.5, 0.05, pot.density, method="Stormer-Verlet")

@@ -1,0 +1,187 @@
+"""The tracer that turns the reference's Python callables (src/HMC.py:52-60: `potential=` / `gradient=`
+lambdas, `grad(potential)`) into potential descriptors -- host logic only (no GPU): what a callable is
+mapped to, and that the generated C++ source (potential + symbolic gradient) computes the callable's
+values.  The source is compiled for the HOST by the test oracle (oracle/oracle.py::pot_custom, the same
+text the device plugin is built from) and compared with the callable evaluated on NUMBERS (on numeric
+input the traceable namespace is NumPy) and with central differences.  The GPU side -- golden fixtures G1
+and G4 through traced potentials -- is tests/test_gpu_parity.py::test_traced_*."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from physicsbasedbayesianinference_amd import trace as jnp
+from physicsbasedbayesianinference_amd.custom import complete_source
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def host_eval(plan, q):
+    assert plan["kind"] == "source"
+    pot = orc.pot_custom(complete_source(plan["source"]), plan["D"])
+    return orc.potential(pot, q, want_grad=True)
+
+
+def central_diff(fn, q, eps=1e-6):
+    g = np.empty_like(q)
+    for j in range(q.shape[0]):
+        for n in range(q.shape[1]):
+            a, b = q[:, n].copy(), q[:, n].copy()
+            a[j] += eps
+            b[j] -= eps
+            g[j, n] = (fn(a) - fn(b)) / (2 * eps)
+    return g
+
+
+# ---- the reference's own idioms ------------------------------------------------------------------
+def test_harmonic_lambda_becomes_the_harmonic_descriptor():
+    """src/tests/test_integrator_harmonic.py:22-24: lambda q: harmonicPotentialND(q, k); grad(...)"""
+    from physicsbasedbayesianinference_amd.potential import harmonicPotentialND
+    k = np.array((2.0, 3.0))
+    harmonicPotential = lambda q: harmonicPotentialND(q, k)   # noqa: E731
+    for kw in ({"potential": harmonicPotential}, {"gradient": jnp.grad(harmonicPotential)},
+               {"potential": lambda q: 0.5 * jnp.dot(k, q ** 2)}, {"gradient": lambda q: k * q}):
+        plan = jnp.plan_potential(D=2, **kw)
+        assert plan["kind"] == "harmonic" and np.array_equal(plan["springConsts"], k)   # exact: Harmonic(k)
+
+
+def test_multivariate_normal_lambdas_become_gaussian_dense():
+    """src/tests/test_HMC.py:48-49,124-125: densityFunc / potentialFunc on multivariate_normal"""
+    mean, cov = np.ones(2) * 5, np.array([[4.0, -3.0], [-3.0, 4.0]])
+    pot_fn = lambda q: -jnp.multivariate_normal.logpdf(q, mean, cov=cov)   # noqa: E731
+    den_fn = lambda q: jnp.multivariate_normal.pdf(q, mean, cov=cov)       # noqa: E731
+    for kw in ({"potential": pot_fn}, {"density": den_fn}):
+        plan = jnp.plan_potential(D=2, **kw)
+        assert plan["kind"] == "gauss_dense" and plan["const_extra"] == 0.0
+        assert np.array_equal(plan["mean"], mean) and np.array_equal(plan["cov"], cov)
+    plan = jnp.plan_potential(lambda q: 1.25 - jnp.multivariate_normal.logpdf(q, mean, cov=cov), D=2)
+    assert plan["kind"] == "gauss_dense" and plan["const_extra"] == 1.25
+    # numeric input: SciPy's values
+    from scipy.stats import multivariate_normal as mvn
+    assert pot_fn(np.array([1.0, 2.0])) == -mvn.logpdf([1.0, 2.0], mean, cov)
+
+
+def test_density_only_standard_gaussian():
+    """src/tests/test_HMC.py:27-33: density(x) = exp(-0.5 |x|^2) / sqrt(2 pi), potential = -log density"""
+    density = lambda x: jnp.exp(-0.50 * jnp.linalg.norm(x) ** 2) / jnp.sqrt(2 * jnp.pi)   # noqa: E731
+    plan = jnp.plan_potential(density=density, D=3)
+    assert plan["kind"] == "gauss_diag"
+    assert np.array_equal(plan["prec"], np.ones(3)) and not np.any(plan["mean"])
+    assert abs(plan["const"] - 0.5 * math.log(2 * math.pi)) < 1e-15
+    assert density(np.array([0.3, -0.2, 0.1])) == np.exp(-0.5 * np.linalg.norm([0.3, -0.2, 0.1]) ** 2) / np.sqrt(2 * np.pi)
+
+
+def test_written_out_quadratic_form_is_recognised():
+    rs = np.random.RandomState(3)
+    D = 6
+    A = rs.standard_normal((D, D))
+    P = np.linalg.inv(A @ A.T / D + np.eye(D))
+    P = 0.5 * (P + P.T)
+    mu = rs.standard_normal(D)
+    plan = jnp.plan_potential(lambda q: 0.5 * (q - mu) @ P @ (q - mu) + 0.75, D=D)
+    assert plan["kind"] == "gauss_dense"
+    assert np.allclose(plan["precision"], P, rtol=1e-14, atol=1e-15) and np.allclose(plan["mean"], mu, atol=1e-13)
+    assert abs(plan["const"] - 0.75) < 1e-13
+    plan = jnp.plan_potential(lambda q: 0.5 * jnp.dot(q, jnp.dot(P, q)), D=D)   # zero mean: P exactly
+    assert plan["kind"] == "gauss_dense" and np.array_equal(plan["precision"], P) and not np.any(plan["mean"])
+    # a concave direction has no Gaussian descriptor: generated source instead
+    assert jnp.plan_potential(lambda q: q[0] * q[0] - q[1] * q[1], D=2)["kind"] == "source"
+
+
+# ---- generated source ---------------------------------------------------------------------------
+def softplus(z):
+    return jnp.maximum(z, 0.0) + jnp.log1p(jnp.exp(-jnp.abs(z)))
+
+
+X_DATA = np.random.RandomState(5).standard_normal((12, 4))
+Y_DATA = (np.random.RandomState(6).uniform(size=12) < 0.5).astype(float)
+
+CASES = {
+    "quartic_tanh": (3, lambda q: jnp.sum(jnp.log1p(jnp.exp(-q)) + 0.25 * q ** 4) + jnp.tanh(q[0] * q[1])),
+    "logistic_regression": (4, lambda w: jnp.sum(softplus(X_DATA @ w) - Y_DATA * (X_DATA @ w)) + 0.5 * jnp.dot(w, w)),
+    "trig_div_sqrt": (3, lambda q: jnp.sin(q[0]) * jnp.cos(q[1]) / (2.0 + q[2] ** 2) + jnp.sqrt(1.0 + q[0] ** 2)
+                      + (1.5 + q[1] ** 2) ** 1.5 + 3.0 / (1.0 + jnp.exp(-q[2]))),
+    "where_abs_min": (2, lambda q: jnp.where(q[0] > 0.3, q[0] ** 2, -q[0]) + jnp.abs(q[1]) ** 3
+                      + jnp.minimum(q[0], q[1]) ** 2 + jnp.logaddexp(q[0], 2.0 * q[1])),
+    "rosenbrock": (5, lambda q: jnp.sum(100.0 * (q[1:] - q[:-1] ** 2) ** 2 + (1.0 - q[:-1]) ** 2) / 20.0),
+    "norm_logpdf": (3, lambda q: -jnp.sum(jnp.norm.logpdf(q, loc=np.array([0.5, -1.0, 2.0]), scale=1.5))
+                    + jnp.sum(q ** 4)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_generated_source_computes_the_callable(name):
+    D, fn = CASES[name]
+    plan = jnp.plan_potential(fn, D=D)
+    assert plan["kind"] == "source"
+    q = np.random.RandomState(11).standard_normal((D, 7)) * 0.8 + 0.2
+    U, g = host_eval(plan, q)
+    ref = np.array([fn(q[:, n]) for n in range(q.shape[1])])          # NumPy on numbers
+    assert np.allclose(U, ref, rtol=1e-13, atol=1e-13), np.max(np.abs(U - ref))
+    fd = central_diff(fn, q)
+    assert np.allclose(g, fd, rtol=2e-6, atol=2e-6), np.max(np.abs(g - fd))
+
+
+def test_hand_written_gradient_callable_is_used_as_written():
+    D = 3
+    fn = lambda q: jnp.sum(0.25 * q ** 4)          # noqa: E731
+    gr = lambda q: q ** 3 + 0.0 * q[::-1]          # noqa: E731  (marker: mentions the reversed vector)
+    plan = jnp.plan_potential(fn, D=D, gradient=gr)
+    q = np.random.RandomState(2).standard_normal((D, 5))
+    U, g = host_eval(plan, q)
+    assert np.allclose(U, 0.25 * np.sum(q ** 4, axis=0), rtol=1e-14)
+    assert np.allclose(g, q ** 3, rtol=1e-14)
+    # a gradient alone that is not linear: source whose potential reads NaN (integrate() needs no potential)
+    plan = jnp.plan_potential(gradient=gr, D=D)
+    U, g = host_eval(plan, q)
+    assert np.all(np.isnan(U)) and np.allclose(g, q ** 3, rtol=1e-14)
+
+
+def test_gaussians_through_the_generic_path():
+    """prefer="source": what the GPU tests push golden G1 / G4 through."""
+    k = np.array((2.0, 3.0))
+    plan = jnp.plan_potential(lambda q: 0.5 * jnp.dot(k, q ** 2), D=2, prefer="source")
+    q = np.random.RandomState(1).standard_normal((2, 9)) * 3
+    U, g = host_eval(plan, q)
+    assert np.allclose(U, 0.5 * (k[:, None] * q ** 2).sum(0), rtol=1e-15) and np.array_equal(g, k[:, None] * q)
+    mean, cov = np.array([5.0, 4.0]), np.array([[4.0, -3.0], [-3.0, 4.0]])
+    plan = jnp.plan_potential(lambda x: -jnp.multivariate_normal.logpdf(x, mean, cov=cov), D=2, prefer="source")
+    from scipy.stats import multivariate_normal as mvn
+    U, g = host_eval(plan, q)
+    assert np.allclose(U, -mvn.logpdf(q.T, mean, cov), rtol=1e-13)
+    assert np.allclose(g, np.linalg.inv(cov) @ (q - mean[:, None]), rtol=1e-13)
+
+
+# ---- what cannot be traced raises (there is no fallback) -----------------------------------------
+@pytest.mark.parametrize("fn", [lambda q: math.exp(q[0]), lambda q: np.exp(q).sum(), lambda q: float(q[0]) ** 2,
+                                lambda q: q[0] if q[0] > 0 else -q[0], lambda q: "text", lambda q: q],
+                         ids=["math.exp", "numpy_ufunc", "float()", "python_if", "not_a_number", "not_a_scalar"])
+def test_untraceable_callables_raise_typeerror(fn):
+    with pytest.raises(TypeError):
+        jnp.plan_potential(fn, D=2)
+
+
+def test_resolve_potential_without_a_dimension_still_rejects_callables():
+    from physicsbasedbayesianinference_amd.integrator import resolve_potential
+    with pytest.raises(TypeError):
+        resolve_potential(lambda q: q, "gradient")
+
+
+def test_dropin_jax_names_resolve_to_the_tracer():
+    """`import jax.numpy as jnp; from jax import grad; from jax.scipy.stats import multivariate_normal`
+    (src/tests/test_HMC.py:13-22) with dropin/ on sys.path."""
+    import subprocess
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import jax, jax.numpy as jnp\nfrom jax import grad\nfrom jax.scipy.stats import multivariate_normal\n"
+            "jax.config.update('jax_enable_x64', True)\n"
+            "from physicsbasedbayesianinference_amd import trace\n"
+            "assert jnp.dot is trace.dot and multivariate_normal is trace.multivariate_normal\n"
+            "assert isinstance(grad(lambda q: jnp.sum(q ** 2)), trace.TracedGradient)\n"
+            "print(trace.plan_potential(grad(lambda q: jnp.sum(q ** 2)), D=2)['kind'])\n"
+            % (ROOT, os.path.join(ROOT, "dropin")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "harmonic"
