@@ -408,6 +408,10 @@ def bench_c2(args, rank, world, local_rank):
     chain0 = rank * N
     seed = 42
     stream = torch.cuda.current_stream().cuda_stream
+    # --draw f64: momenta from the double-precision draw of the RNG contract (PBBI_DRAW_F64, include/pbbi.h),
+    # the counterpart of the reference's float64 normals; default: the single-precision draw
+    f64 = getattr(args, "draw", "f32") == "f64"
+    run_flags = _lib.COMPAT_P_FROM_OLDQ | (_lib.DRAW_F64 if f64 else 0)
 
     q_state = torch.empty((D, N), dtype=torch.float64, device=f"cuda:{dev}")
     _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, chain0, D, N, N, 1.0, None,
@@ -422,7 +426,7 @@ def bench_c2(args, rank, world, local_rank):
             s = min(S, S_alloc)
             _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q_state.data_ptr(), None,
                       samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), None, N, N, STEP, L,
-                      s, _lib.COMPAT_P_FROM_OLDQ, seed, iter0, chain0, 1.0, stream)
+                      s, run_flags, seed, iter0, chain0, 1.0, stream)
             S, iter0 = S - s, iter0 + s
 
     def barrier():
@@ -491,7 +495,9 @@ def bench_c2(args, rank, world, local_rank):
                                "per HMC iteration, in-kernel Philox momentum + Metropolis",
                    "chains_per_gpu": N, "total_chains": total_chains, "D": D, "L": L,
                    "stepSize": STEP, "parallelism": f"ensemble-sharded x{world}",
-                   "accept_rate": accept},
+                   "accept_rate": accept,
+                   "draw": "f64 (PBBI_DRAW_F64: double-precision Box-Muller, bit-identical to the oracle)" if f64
+                   else "f32 (single-precision Box-Muller on the transcendental unit; momenta only)"},
         "roofline": roofline(
             "mfma", "k_dense_hmc<8, full, hmc, zero-mean" + (", carried gradient, fused iterations>" if carried else ">"),
             FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", kernel_s, kernel_ss, flops_exec, flops_launch,
@@ -552,6 +558,8 @@ def main():
     ap.add_argument("--potential", default="rosenbrock", choices=["rosenbrock", "diag"],
                     help="--workload stream: potential")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
+    ap.add_argument("--draw", default="f32", choices=["f32", "f64"],
+                    help="--workload c2: precision of the in-kernel momentum draw (f64 = PBBI_DRAW_F64)")
     ap.add_argument("--rng", default="philox", choices=["philox", "numpy"],
                     help="--workload c2 --rng numpy = --workload parity: C2 through the class API's default "
                          "mode (the reference's NumPy stream drawn on the host)")
@@ -598,7 +606,12 @@ def main():
         out = bench_c2(args, rank, world, local_rank)
         if rank == 0 and world == 1 and not args.no_extras:
             extras = {}
-            for name, fn in (("c3_kdk_fma", lambda: bench_c3(args, False)),
+            def c2_f64():
+                a2 = argparse.Namespace(**vars(args))
+                a2.draw, a2.no_cpu_baseline = "f64", True
+                return bench_c2(a2, rank, world, local_rank)
+            for name, fn in (("c2_draw_f64", c2_f64),
+                             ("c3_kdk_fma", lambda: bench_c3(args, False)),
                              ("c3_exact_order", lambda: bench_c3(args, True)),
                              ("c5", lambda: bench_c5(args)),
                              # the drop-in's default mode (the reference's NumPy stream, bit-exact): 30 iterations

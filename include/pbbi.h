@@ -42,6 +42,16 @@
  *     The device evaluates log2/sqrt/sin/cos on its transcendental unit; draws are
  *     reproducible bit for bit on the device (pbbi_philox_normal returns exactly what
  *     pbbi_hmc_run draws), exact N(0,1) on a 2^-24-relative grid with tails to 6.7 sigma.
+ *   Flag PBBI_DRAW_F64 (stream bit PBBI_STREAM_DRAW_F64 of pbbi_philox_normal): DOUBLE-PRECISION Box-Muller,
+ *     the counterpart of the reference's float64 draws (src/ensemble.py:72-74,88-91).  Two blocks per four
+ *     dims: slots 0,1 from block blk, slots 2,3 from block blk | 0x80000000.  With w1 = x1:x0, w2 = x3:x2:
+ *       u1 = ((w1 >> 12) + 0.5) * 2^-52 in (0,1);   k2 = w2 >> 11,  angle 2 pi k2 2^-53 = (pi/2)(n + y),
+ *       n = (k2 + 2^50) >> 51,  y = (k2 - n 2^51) 2^-51 in [-1/2, 1/2)   (integer arithmetic, exact);
+ *       r = sqrt(-2 ln u1), ln by fdlibm's e_log.c scheme (s = f/(2+f), Lg1..Lg7, Horner with fma);
+ *       sin / cos((pi/2) y) by Taylor polynomials in y^2 (9 / 10 terms, fma), rotated by n & 3;
+ *       z_even = r cos(angle),  z_odd = r sin(angle).
+ *     Only +, -, *, /, sqrt, fma in a fixed order: the device's variates and the oracle's are THE SAME BITS
+ *     (csrc/pbbi_rng.h, oracle/pbbi_oracle.c); exact N(0,1) on a 2^-52 grid with tails to 8.57 sigma.
  *   Metropolis uniform of a chain: block = 0xFFFFFFFF, stream = PBBI_STREAM_UNIFORM,
  *     u = ((x1:x0)>>11) * 2^-53 in [0,1).
  *   The integer part is bit-identical to oracle/pbbi_oracle.c; the single-precision
@@ -56,7 +66,7 @@
 extern "C" {
 #endif
 
-#define PBBI_VERSION 102 /* major*100 + minor */
+#define PBBI_VERSION 103 /* major*100 + minor */
 
 enum { PBBI_OK = 0, PBBI_ERR_INVALID = -1, PBBI_ERR_UNSUPPORTED = -2, PBBI_ERR_HIP = -3 };
 enum { PBBI_F64 = 0, PBBI_F32 = 1 };
@@ -94,9 +104,16 @@ enum {
      * warm-up (HMC.adaptTrajectoryLength), not for the recorded run.  Lanes of finished chains are
      * masked out; a wave leaves the loop when its last chain has. */
     PBBI_PER_CHAIN_STEPS = 8,
-    PBBI_UTURN_STOP = 16
+    PBBI_UTURN_STOP = 16,
+    /* Momenta drawn in DOUBLE precision (pbbi_hmc_run / pbbi_hmc_run_dyn, every kernel family): the
+     * counterpart of the reference's float64 normals (src/ensemble.py:72-74,88-91).  See "RNG contract":
+     * bit-identical to oracle/pbbi_oracle.c, 52-bit radius / 53-bit angle, tails to 8.57 sigma.  Costs
+     * ~2.5x the vector instructions of the default single-precision draw (the C2 headline: see DESIGN.md). */
+    PBBI_DRAW_F64 = 32
 };
-enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2, PBBI_STREAM_STEPS = 3 };
+enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2, PBBI_STREAM_STEPS = 3,
+       /* OR-ed into pbbi_philox_normal's rng_stream: the draw PBBI_DRAW_F64 selects in pbbi_hmc_run */
+       PBBI_STREAM_DRAW_F64 = 0x100 };
 
 typedef struct pbbi_potential pbbi_potential; /* opaque */
 

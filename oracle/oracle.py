@@ -22,6 +22,8 @@ HARMONIC, GAUSS_DIAG, GAUSS_DENSE, ROSENBROCK, CUSTOM = 0, 1, 2, 3, 4
 LEAPFROG, STORMER_VERLET = 0, 1
 COMPAT_P_FROM_OLDQ = 1
 BETA_ACCEPT = 4
+DRAW_F64 = 32          # PBBI_DRAW_F64: double-precision Box-Muller (include/pbbi.h)
+STREAM_DRAW_F64 = 0x100  # the same as a bit of the stream argument of philox_normal
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM = 0, 1, 2
 METHODS = {"Leapfrog": LEAPFROG, "Stormer-Verlet": STORMER_VERLET}
 

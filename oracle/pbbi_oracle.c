@@ -33,7 +33,7 @@
 enum { POT_HARMONIC = 0, POT_GAUSS_DIAG = 1, POT_GAUSS_DENSE = 2, POT_ROSENBROCK = 3, POT_CUSTOM = 4 };
 enum { METHOD_LEAPFROG = 0, METHOD_STORMER_VERLET = 1 };
 /* compat flag bit 0: reproduce src/HMC.py:176 (rejected momentum <- oldQ) */
-enum { COMPAT_P_FROM_OLDQ = 1, BETA_ACCEPT = 4 /* include/pbbi.h: PBBI_BETA_ACCEPT */ };
+enum { COMPAT_P_FROM_OLDQ = 1, BETA_ACCEPT = 4 /* include/pbbi.h: PBBI_BETA_ACCEPT */, DRAW_F64 = 32 /* PBBI_DRAW_F64 */ };
 
 typedef struct {
     int kind;
@@ -500,6 +500,92 @@ static void box_muller_f32(uint32_t a, uint32_t b, float* zc, float* zs) {
     *zs = r * (float)sin(ang);
 }
 
+/* ---- double-precision draw (flag PBBI_DRAW_F64 / stream bit 0x100; include/pbbi.h "RNG contract").
+ * Restated here in plain C from the contract's text: the transform is built from +, -, *, /, sqrt and fma
+ * only (each correctly rounded on the host and on gfx950) in a FIXED order, so the device's variates and
+ * these agree bit for bit -- unlike the single-precision draw, whose transcendental unit has no host twin.
+ *   w1 = x1:x0, w2 = x3:x2 of ONE Philox block;
+ *   u1 = ((w1 >> 12) + 0.5) * 2^-52  in (0, 1)   (tails to 8.57 sigma);
+ *   k2 = w2 >> 11 (53 bits), angle = 2 pi k2 2^-53 = (pi/2)(n + y),  n = (k2 + 2^50) >> 51,
+ *        y = (k2 - n 2^51) 2^-51 in [-1/2, 1/2)  (exact integer arithmetic);
+ *   r = sqrt(-2 ln u1): ln by fdlibm's e_log.c scheme (u = 2^k m, m in [sqrt(1/2), sqrt 2), f = m - 1,
+ *        s = f / (2 + f), minimax polynomial in s^2 with the Lg1..Lg7 of that file, Horner with fma);
+ *   sin / cos((pi/2) y): Taylor polynomials in y^2 (9 / 10 terms, coefficients (pi/2)^j / j! rounded from
+ *        60-digit decimals by tools/gen_draw_coeffs.py), Horner with fma; rotated by the quadrant n & 3;
+ *   z_even = r cos(angle), z_odd = r sin(angle).
+ * Block use: the four dims {d, d+4, d+8, d+12} of a group of 16 take blk = ((dim>>4)<<2)|(dim&3) for slots
+ * 0, 1 and blk | 0x80000000 for slots 2, 3 (two blocks where the single-precision draw needs one). */
+static double draw_log_unit(double u) { /* ln u, u a normal double in (0, 1] */
+    static const double ln2_hi = 0x1.62e42fee00000p-1, ln2_lo = 0x1.a39ef35793c76p-33,
+                        Lg1 = 0x1.5555555555593p-1, Lg2 = 0x1.999999997fa04p-2, Lg3 = 0x1.2492494229359p-2,
+                        Lg4 = 0x1.c71c51d8e78afp-3, Lg5 = 0x1.7466496cb03dep-3, Lg6 = 0x1.39a09d078c69fp-3,
+                        Lg7 = 0x1.2f112df3e5244p-3;
+    uint64_t bits;
+    memcpy(&bits, &u, 8);
+    int k = (int)(bits >> 52) - 1023;
+    const uint64_t mant = bits & 0xFFFFFFFFFFFFFull;
+    uint64_t mb;
+    if (mant > 0x6A09E667F3BCCull) { k += 1; mb = mant | (1022ull << 52); }
+    else mb = mant | (1023ull << 52);
+    double m;
+    memcpy(&m, &mb, 8);
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+static void draw_sincos_quarter(double y, double* sn, double* cs) { /* sin, cos of (pi/2) y, |y| <= 1/2 */
+    static const double S[9] = {0x1.921fb54442d18p+0, -0x1.4abbce625be53p-1, 0x1.466bc6775aae2p-4,
+                                -0x1.32d2cce62bd86p-8, 0x1.50783487ee782p-13, -0x1.e3074fde8871fp-19,
+                                0x1.e8f434d018d63p-25, -0x1.6fadb9f155744p-31, 0x1.aaec32af93359p-38};
+    static const double Cc[10] = {0x1.0000000000000p+0, -0x1.3bd3cc9be45dep+0, 0x1.03c1f081b5ac4p-2,
+                                  -0x1.55d3c7e3cbffap-6, 0x1.e1f506891babbp-11, -0x1.a6d1f2a204a8cp-16,
+                                  0x1.f9d38a3763cc3p-22, -0x1.b6e24f44b128fp-28, 0x1.20c62c2f2d7f5p-34,
+                                  -0x1.2a0c591af8314p-41};
+    const double z = y * y;
+    double s = S[8], c = Cc[9];
+    for (int k = 7; k >= 0; --k) s = fma(s, z, S[k]);
+    for (int k = 8; k >= 0; --k) c = fma(c, z, Cc[k]);
+    *sn = y * s;
+    *cs = c;
+}
+
+static void box_muller_f64(const uint32_t x[4], double* zc, double* zs) {
+    const uint64_t w1 = ((uint64_t)x[1] << 32) | x[0], w2 = ((uint64_t)x[3] << 32) | x[2];
+    const double u1 = ((double)(w1 >> 12) + 0.5) * 0x1.0p-52;
+    const uint64_t k2 = w2 >> 11;
+    const uint64_t n = (k2 + (1ull << 50)) >> 51;
+    const double y = (double)((int64_t)k2 - (int64_t)(n << 51)) * 0x1.0p-51;
+    double sn, cs;
+    draw_sincos_quarter(y, &sn, &cs);
+    const double r = sqrt(-2.0 * draw_log_unit(u1));
+    double c, s;
+    switch ((int)(n & 3)) {
+        case 0: c = cs; s = sn; break;
+        case 1: c = -sn; s = cs; break;
+        case 2: c = -cs; s = -sn; break;
+        default: c = sn; s = -cs; break;
+    }
+    *zc = r * c;
+    *zs = r * s;
+}
+
+static double rng_normal_f64(uint64_t seed, uint32_t stream, uint64_t iter, uint64_t chain, int dim) {
+    uint32_t x[4];
+    double z[2];
+    const int slot = (dim >> 2) & 3;
+    const uint32_t blk = (uint32_t)(((dim >> 4) << 2) | (dim & 3)) | (slot >= 2 ? 0x80000000u : 0u);
+    rng_block(seed, stream, iter, chain, blk, x);
+    box_muller_f64(x, &z[0], &z[1]);
+    return z[slot & 1];
+}
+
 /* standard normal for element (dim, chain) of draw `iter` in `stream`:
  *   block index blk = ((dim >> 4) << 2) | (dim & 3): dims d, d+4, d+8, d+12 (same d mod 4
  *   inside a group of 16) share a block; slot = (dim >> 2) & 3 picks
@@ -530,15 +616,18 @@ int oracle_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N
     return 0;
 }
 
-/* out[d*ldn + n] = scale_n * z(d, chain0 + n); scale (N) optional else scalar */
+/* out[d*ldn + n] = scale_n * z(d, chain0 + n); scale (N) optional else scalar.
+ * stream | 0x100 (PBBI_STREAM_DRAW_F64): the double-precision draw above. */
 int oracle_philox_normal(uint64_t seed, int stream, uint64_t iter, uint64_t chain0, int D, int64_t N,
                          int64_t ldn, double scale_scalar, const double* scale_per_chain,
                          double* out) {
+    const int f64 = (stream & 0x100) != 0;
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         const double sc = scale_per_chain ? scale_per_chain[n] : scale_scalar;
         for (int d = 0; d < D; ++d)
-            out[(size_t)d * ldn + n] = rng_normal(seed, (uint32_t)stream, iter, chain0 + n, d) * sc;
+            out[(size_t)d * ldn + n] = (f64 ? rng_normal_f64(seed, (uint32_t)stream, iter, chain0 + n, d)
+                                            : rng_normal(seed, (uint32_t)stream, iter, chain0 + n, d)) * sc;
     }
     return 0;
 }
@@ -565,7 +654,8 @@ int oracle_hmc_run_philox(const oracle_pot* P, int method, double* q, const doub
     for (int64_t n = 0; n < N; ++n) pstd[n] = sqrt((mass ? mass[n] : 1.0) * kT);
     int rc = 0;
     for (int i = 0; i < S && rc == 0; ++i) {
-        oracle_philox_normal(seed, STREAM_MOMENTUM, iter0 + i, chain0, D, N, ldn, 1.0, pstd, p);
+        oracle_philox_normal(seed, STREAM_MOMENTUM | ((compat & DRAW_F64) ? 0x100 : 0), iter0 + i, chain0, D, N,
+                             ldn, 1.0, pstd, p);
         oracle_philox_uniform(seed, iter0 + i, chain0, N, u);
         rc = oracle_hmc_iter_beta(P, method, q, p, u, mass, N, ldn, h, L, compat,
                                   (compat & BETA_ACCEPT) ? 1.0 / kT : 1.0,

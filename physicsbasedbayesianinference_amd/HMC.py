@@ -188,7 +188,7 @@ WARMUP_SEED_MASK = 0xA5A55A5ADA7A0001
 class HMC:
     def __init__(self, ensemble, simulTime, stepSize, density, potential=None, gradient=None,
                  method="Leapfrog", compat=True, rng="numpy", seed=0, verbose=True, kdk_fma=None,
-                 beta_accept=False):
+                 beta_accept=False, draw_f64=False):
         self.ensemble = ensemble
         self.simulTime = simulTime
         self.stepSize = stepSize
@@ -197,6 +197,9 @@ class HMC:
         # PBBI_BETA_ACCEPT (include/pbbi.h): accept with exp((oldH - newH) / (kB*T)), the test that
         # matches the momentum draw at kB*T; default off = the reference's exp(oldH - newH)
         self.beta_accept = bool(beta_accept)
+        # PBBI_DRAW_F64 (rng="philox"): positions and momenta drawn in double precision, the counterpart of
+        # the reference's float64 normals (src/ensemble.py:72-74,88-91); default: the single-precision draw
+        self.draw_f64 = bool(draw_f64)
         # PBBI_KDK_FMA, the throughput form of Leapfrog (include/pbbi.h): default on in the
         # throughput RNG mode, off in the reference-parity mode
         self.kdk_fma = (rng == "philox") if kdk_fma is None else bool(kdk_fma)
@@ -265,7 +268,10 @@ class HMC:
 
     def _flags(self):
         return ((_lib.COMPAT_P_FROM_OLDQ if self.compat else 0) | (_lib.KDK_FMA if self.kdk_fma else 0) |
-                (_lib.BETA_ACCEPT if self.beta_accept else 0))
+                (_lib.BETA_ACCEPT if self.beta_accept else 0) | (_lib.DRAW_F64 if self.draw_f64 else 0))
+
+    def _position_stream(self):
+        return _lib.STREAM_POSITION | (_lib.STREAM_DRAW_F64 if self.draw_f64 else 0)
 
     def ensembleWeights(self, q, p, temperature=None):
         """Normalised canonical weights of the ensemble, w_n = exp(-beta H_n) / sum_m exp(-beta H_m)
@@ -418,7 +424,7 @@ class HMC:
         elif rng == "philox":
             kT = float(boltzmannConst * temperature)                         # src/ensemble.py:88
             q_state = empty((D, N), dt, dev)
-            _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D,
+            _lib.call("pbbi_philox_normal", seed, self._position_stream(), int(iter0), int(chain0), D,
                       N, N, float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
             if burn_in:
                 if jitter:
@@ -494,7 +500,7 @@ class HMC:
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
         q_state = empty((D, N), dt, dev)
-        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, int(iter0), int(chain0), D, N, N,
+        _lib.call("pbbi_philox_normal", seed, self._position_stream(), int(iter0), int(chain0), D, N, N,
                   float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
         c_alloc = min(chunk, max(S, 1))
         samples = empty((c_alloc, D, N), dt, dev)
@@ -547,7 +553,7 @@ class HMC:
         ratio = empty((1, N), dt, dev)  # burn-in form of pbbi_hmc_run: no sample slab
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
-        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, int(chain0), D, N, N,
+        _lib.call("pbbi_philox_normal", seed, self._position_stream(), 0, int(chain0), D, N, N,
                   float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
         sharded = torch.distributed.is_available() and torch.distributed.is_initialized()
         h = float(self.stepSize)
@@ -598,7 +604,7 @@ class HMC:
         q_state = empty((D, N), dt, dev)
         steps = empty((int(iterations), N), np.int32, dev)
         md = self._mass()
-        _lib.call("pbbi_philox_normal", seed, _lib.STREAM_POSITION, 0, int(chain0), D, N, N, float(qStd), None,
+        _lib.call("pbbi_philox_normal", seed, self._position_stream(), 0, int(chain0), D, N, N, float(qStd), None,
                   pot._dt, dev, q_state.data_ptr(), stream)
         _lib.call("pbbi_hmc_run_dyn", pot.handle, self.integrator.method_id, q_state.data_ptr(),
                   md.data_ptr() if md is not None else None, None, None, None, None, steps.data_ptr(), N, N,

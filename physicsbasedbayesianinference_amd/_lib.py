@@ -18,7 +18,9 @@ KDK_FMA = 2
 BETA_ACCEPT = 4
 PER_CHAIN_STEPS = 8
 UTURN_STOP = 16
+DRAW_F64 = 32            # momenta drawn in double precision (include/pbbi.h)
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM, STREAM_STEPS = 0, 1, 2, 3
+STREAM_DRAW_F64 = 0x100  # OR-ed into pbbi_philox_normal's rng_stream: the draw DRAW_F64 selects
 
 
 class PbbiError(RuntimeError):

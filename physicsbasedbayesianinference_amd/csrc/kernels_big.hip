@@ -725,20 +725,20 @@ __global__ void k_big_sq_partial(const T* a, int64_t ld, int D, int64_t N, int r
 template <typename T>
 __global__ void k_big_momentum(const T* p_in, int64_t ldp, T* vh, T* p_keep, int64_t ldw, int D,
                                int64_t N, const T* mass, int rng, uint64_t seed, uint64_t iter,
-                               uint64_t chain0, double kT) {
+                               uint64_t chain0, double kT, int draw64) {
     // one thread per (block of 4 dims sharing a Philox block, chain)
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = blockIdx.y;  // Philox block index: dims 16*(blk>>2) + (blk&3) + 4*slot
     if (n >= N) return;
     const double m = mass ? (double)mass[n] : 1.0;
     const double pstd = sqrt(m * kT);
-    float z[4];
-    if (rng) rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain0 + (uint64_t)n, (uint32_t)blk, z);
+    double z[4];
+    if (rng) rng_normal4d(seed, PBBI_STREAM_MOMENTUM, iter, chain0 + (uint64_t)n, (uint32_t)blk, draw64 != 0, z);
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         const int d = 16 * (blk >> 2) + (blk & 3) + 4 * sl;
         if (d < D) {
-            const T p = rng ? (T)((double)z[sl] * pstd) : p_in[(int64_t)d * ldp + n];
+            const T p = rng ? (T)(z[sl] * pstd) : p_in[(int64_t)d * ldp + n];
             if (p_keep) p_keep[(int64_t)d * ldw + n] = p;  // drawn momentum (needed for pp_old / rejects)
             vh[(int64_t)d * ldw + n] = mass ? (T)(p * (T)(1.0 / m)) : p;
         }
@@ -962,7 +962,7 @@ int run_hmc(const IterArgs& a) {
     const int n_blk = ((D + 15) / 16) * 4;
     hipLaunchKernelGGL(k_big_momentum<T>, dim3(g1.x, (unsigned)n_blk), b1, 0, st, (const T*)a.p_in,
                        a.ldn_in, vh, pdraw, N, D, N, (const T*)a.mass, a.rng, a.seed, a.iter,
-                       a.chain0, a.kT);
+                       a.chain0, a.kT, (a.flags & PBBI_DRAW_F64) ? 1 : 0);
     hipLaunchKernelGGL(k_big_sq_partial<T>, dim3(g1.x, (unsigned)n_sq), b1, 0, st, (const T*)pdraw,
                        (int64_t)N, D, N, SQ_ROWS, pp_old);
     const T h = (T)a.h, hh = (T)(0.5 * a.h);

@@ -45,12 +45,6 @@
 
 namespace {
 
-#ifdef PBBI_DRAW_F64
-typedef double draw_t;  // diagnostic build: the cost of a double-precision draw (pbbi_rng.h)
-#else
-typedef float draw_t;
-#endif
-
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -276,11 +270,12 @@ __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
             const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
 #pragma unroll
             for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g
-                draw_t z[4];
-                rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g), z);
+                double z[4];
+                rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((k << 2) | g),
+                             (prm.flags & PBBI_DRAW_F64) != 0, z);
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)
-                    v[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? (double)z[sl] * pstd : 0.0;
+                    v[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? z[sl] * pstd : 0.0;
             }
             u = rng_uniform(prm.seed, prm.iter, chain);
             if (have_pout && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid) {
@@ -533,8 +528,11 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 // first iteration of a run (forms g(q_0), stores it as slab 0), CARRY = 2 every later one.  The values
 // are the ones the mat-vec would produce again -- same instructions on the same q -- so a run's samples
 // do not change by a bit.
+// DRAW: which momentum draw is compiled in -- 0 single precision only, 1 PBBI_DRAW_F64 only, 2 both behind a
+// run-time (wave-uniform) branch.  The fused launch exists as 0 and 1 (the branch costs it 18 spilled
+// registers), everything else as 2.
 template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, bool DYN = false, int CARRY = 0,
-          bool FUSE = false>
+          bool FUSE = false, int DRAW = 2>
 __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     static_assert(CARRY == 0 || (MODE == 0 && METHOD == PBBI_LEAPFROG && !DYN), "carry: plain Leapfrog iterations");
     static_assert(!FUSE || CARRY == 2, "a fused launch reads the carried gradient (its first iteration may form it)");
@@ -688,13 +686,14 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     if (rng) {
         const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
         const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
+        const bool draw64 = DRAW == 2 ? (prm.flags & PBBI_DRAW_F64) != 0 : DRAW == 1;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < KS / 4; ++k) {  // block k: rows 16k + 4*slot + g, slot = 0..3
-            draw_t z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((k << 2) | g), z);
+            double z[4];
+            rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((k << 2) | g), draw64, z);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl)
-                vh[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? (double)z[sl] * pstd : 0.0;
+                vh[4 * k + sl] = (FULL || 16 * k + 4 * sl + g < D) ? z[sl] * pstd : 0.0;
         }
         if (prm.p_out && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid) {
             // non-compat: a rejected chain reports its drawn momentum; park the draw in the slab
@@ -1041,9 +1040,14 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
             if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>), grid2, block2, lds, \
                                stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && F_ && carry == 2 && prm.fuse_S > 1 &&   \
+                   (prm.flags & PBBI_DRAW_F64)) {                                                 \
+            if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 1>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 1>), grid2, block2, lds, \
+                               stream, prm);                                                      \
         } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && F_ && carry == 2 && prm.fuse_S > 1) {   \
-            if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true>, lds)) return rc; \
-            hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true>), grid2, block2, lds, \
+            if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 0>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 0>), grid2, block2, lds, \
                                stream, prm);                                                      \
         } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && carry == 2) {                            \
             if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 2>, lds)) return rc; \

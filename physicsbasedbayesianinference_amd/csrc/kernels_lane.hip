@@ -219,7 +219,7 @@ __device__ __forceinline__ T kinetic(const T (&p)[DMAX], T m) {
 // momentum draw of one chain: one Philox block per four dims (RNG contract, include/pbbi.h)
 template <typename T, int DMAX>
 __device__ __forceinline__ void draw_momentum(T (&p)[DMAX], int D, uint64_t seed, uint64_t iter,
-                                              uint64_t chain, double pstd) {
+                                              uint64_t chain, double pstd, bool f64) {
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) p[d] = T(0);
 #pragma unroll
@@ -227,12 +227,12 @@ __device__ __forceinline__ void draw_momentum(T (&p)[DMAX], int D, uint64_t seed
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (16 * G + r < DMAX) {
-                float z[4];
-                rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), z);
+                double z[4];
+                rng_normal4d(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), f64, z);
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     const int d = 16 * G + r + 4 * sl;
-                    if (d < DMAX) p[d] = (d < D) ? (T)((double)z[sl] * pstd) : T(0);  // D uniform
+                    if (d < DMAX) p[d] = (d < D) ? (T)(z[sl] * pstd) : T(0);  // D uniform
                 }
             }
         }
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
         const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(p_out_k, D, prm.ldn_out, prm.N, n0);
         T u;
         if (prm.rng) {
-            draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd);
+            draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd, (prm.flags & PBBI_DRAW_F64) != 0);
             u = (T)rng_uniform(prm.seed, iter_k, chain);
         } else {
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_hmc(HmcPrm<T> prm, Pot pot) {
 #pragma unroll
                     for (int d = 0; d < DMAX; ++d) p[d] = q[d];
                 } else if (prm.rng) {
-                    draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd);
+                    draw_momentum<T, DMAX>(p, D, prm.seed, iter_k, chain, pstd, (prm.flags & PBBI_DRAW_F64) != 0);
                 } else {
 #pragma unroll
                     for (int d = 0; d < DMAX; ++d)
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_dyn_hmc(DynPrm<T> dp, Pot pot) {
     T u;
     int Ln = prm.L;
     if (prm.rng) {
-        draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
+        draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd, (prm.flags & PBBI_DRAW_F64) != 0);
         u = (T)rng_uniform(prm.seed, prm.iter, chain);
         if (prm.flags & PBBI_PER_CHAIN_STEPS) Ln = prm.L > 0 ? rng_steps(prm.seed, prm.iter, chain, prm.L) : 0;
     } else {
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(BLOCK) k_lane_dyn_hmc(DynPrm<T> dp, Pot pot) {
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d) p[d] = q[d];
             } else if (prm.rng) {
-                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd);
+                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd, (prm.flags & PBBI_DRAW_F64) != 0);
             } else {
 #pragma unroll
                 for (int d = 0; d < DMAX; ++d) p[d] = load_row<T, FULL>(bp, voff, rin, d, D);

@@ -229,7 +229,9 @@ __device__ __forceinline__ double pp_pair(const double (&p)[DL]) {
 // and the stop at (q_j - q_0) . v_j < 0.  Both lanes of a chain take the same decision (the dot product
 // is summed in dimension order across the halves, like the energies: bit-exact with the oracle's
 // leapfrog_chain_dyn), so they stay paired for the q_16 / carry exchanges inside the masked loop.
-template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
+// DRAW: 0 single-precision momentum draw only, 1 PBBI_DRAW_F64 only, 2 both behind a wave-uniform branch (the
+// kick-drift-kick kernels exist as 0 and 1: the branch costs them registers they do not have at 4 waves / SIMD)
+template <bool UNIT, bool FULL, bool KDK, bool DYN = false, int DRAW = 2>
 __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& pot, int64_t n0, int c,
                                           int half, bool valid, int cc, double (&q)[DL], double& U_carry,
                                           bool have_U, double (&a)[DL], bool& a_valid,
@@ -256,10 +258,11 @@ __device__ __forceinline__ void ros2_tile(const Ros2Prm& prm, const Ros2<FULL>& 
     auto draw = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // this half's group of 16 dims: blocks (half<<2)|r
-            float z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((half << 2) | r), z);
+            double z[4];
+            rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((half << 2) | r),
+                         DRAW == 2 ? (prm.flags & PBBI_DRAW_F64) != 0 : DRAW == 1, z);
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? z[sl] * pstd : 0.0;
         }
     };
     auto load_p = [&]() {
@@ -438,7 +441,7 @@ struct Ros2Run {
 // a wave pays the load once per launch, only samples leave the chip, and waves that share a SIMD
 // drift out of step within a few iterations, so that one wave's draw (32-bit multiplies, xors) and
 // stores run beside another's trajectory (fp64).
-template <bool UNIT, bool FULL, bool KDK, bool DYN = false>
+template <bool UNIT, bool FULL, bool KDK, bool DYN = false, int DRAW = 2>
 __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBBI_ROS2_WAVES_KDK - 1)
                                               : PBBI_ROS2_WAVES_EXACT)
     k_ros2_hmc(Ros2Prm prm, Ros2Run run) {
@@ -478,10 +481,10 @@ __global__ void __launch_bounds__(BLOCK, KDK ? (UNIT ? PBBI_ROS2_WAVES_KDK : PBB
         if constexpr (DYN) {  // (at the register limit: it evaluates U(q_old) and a(q_old) every iteration rather than spill)
             double unused = 0.0, a_dyn[DL];
             bool no = false;
-            ros2_tile<UNIT, FULL, KDK, true>(it, pot, n0, c, half, valid, cc, q, unused, false, a_dyn, no, run.steps_in,
+            ros2_tile<UNIT, FULL, KDK, true, DRAW>(it, pot, n0, c, half, valid, cc, q, unused, false, a_dyn, no, run.steps_in,
                                              run.steps_out);
         } else {
-            ros2_tile<UNIT, FULL, KDK, false>(it, pot, n0, c, half, valid, cc, q, U_carry, k > 0, a_carry, a_valid);
+            ros2_tile<UNIT, FULL, KDK, false, DRAW>(it, pot, n0, c, half, valid, cc, q, U_carry, k > 0, a_carry, a_valid);
         }
     }
 #ifdef PBBI_STAMPS_ROS2
@@ -524,8 +527,10 @@ int lane2_hmc_iter(const IterArgs& a) {
     {                                                                                                \
         if (dyn)                                                                                     \
             hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false, true>), grid, block, 0, a.stream, prm, run); \
+        else if (kdk && (a.flags & PBBI_DRAW_F64))                                                   \
+            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true, false, 1>), grid, block, 0, a.stream, prm, run); \
         else if (kdk)                                                                                \
-            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true>), grid, block, 0, a.stream, prm, run);      \
+            hipLaunchKernelGGL((k_ros2_hmc<U_, F_, true, false, 0>), grid, block, 0, a.stream, prm, run); \
         else                                                                                         \
             hipLaunchKernelGGL((k_ros2_hmc<U_, F_, false>), grid, block, 0, a.stream, prm, run);     \
     }

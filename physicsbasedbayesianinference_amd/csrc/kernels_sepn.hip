@@ -118,10 +118,10 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm, SepRun run) {
     auto draw = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // this part's group of 16 dims: blocks (part<<2)|r
-            float z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((part << 2) | r), z);
+            double z[4];
+            rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((part << 2) | r), (prm.flags & PBBI_DRAW_F64) != 0, z);
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? z[sl] * pstd : 0.0;
         }
     };
     auto load_p = [&]() {
@@ -288,10 +288,10 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_exact_hmc(SepPrm prm) {
     auto draw = [&]() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float z[4];
-            rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), z);
+            double z[4];
+            rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, prm.iter, chain, (uint32_t)((part << 2) | r), (prm.flags & PBBI_DRAW_F64) != 0, z);
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? (double)z[sl] * pstd : 0.0;
+            for (int sl = 0; sl < 4; ++sl) v[r + 4 * sl] = exists(r + 4 * sl) ? z[sl] * pstd : 0.0;
         }
     };
     auto load_p = [&]() {

@@ -87,16 +87,16 @@ __device__ __forceinline__ void load_rows(const T* col, int64_t ld, int j0, int 
 // the momentum of one chain in dimension order: one Philox block per four dims (include/pbbi.h)
 template <typename T, typename F>
 __device__ __forceinline__ void draw_rows(uint64_t seed, uint64_t iter, uint64_t chain, int D,
-                                          double pstd, F&& visit) {
+                                          double pstd, bool f64, F&& visit) {
     for (int G = 0; 16 * G < D; ++G) {
-        float z[4][4];
+        double z[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), z[r]);
+            rng_normal4d(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), f64, z[r]);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int d = 16 * G + k;  // = 16G + r + 4*slot with r = k & 3, slot = k >> 2
-            if (d < D) visit(d, (T)((double)z[k & 3][k >> 2] * pstd));
+            if (d < D) visit(d, (T)(z[k & 3][k >> 2] * pstd));
         }
     }
 }
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(SB) k_stream_hmc(HmcPrm<T> prm, SPot<T> pot) {
     // momentum: v = p/m into the workspace, dot(p, p) in dimension order
     T pp = T(0), u;
     if (prm.rng) {
-        draw_rows<T>(prm.seed, prm.iter, chain, D, pstd, [&](int d, T p) {
+        draw_rows<T>(prm.seed, prm.iter, chain, D, pstd, (prm.flags & PBBI_DRAW_F64) != 0, [&](int d, T p) {
             pp += p * p;
             wv[(int64_t)d * ld] = UNIT ? p : p / m;
         });
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(SB) k_stream_hmc(HmcPrm<T> prm, SPot<T> pot) {
         }
     }
     if (po && reject && !compat && prm.rng)  // the proposal's momentum is the draw of this iteration
-        draw_rows<T>(prm.seed, prm.iter, chain, D, pstd,
+        draw_rows<T>(prm.seed, prm.iter, chain, D, pstd, (prm.flags & PBBI_DRAW_F64) != 0,
                      [&](int d, T p) { po[(int64_t)d * prm.ldn_out] = p; });
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;

@@ -178,7 +178,8 @@ __global__ void k_philox_normal(uint64_t seed, int stream, uint64_t iter, uint64
     if (n >= N) return;
     const double sc = scale_n ? (double)scale_n[n] : scale;
     for (int d = 0; d < D; ++d)
-        out[(int64_t)d * ldn + n] = (T)(rng_normal(seed, (uint32_t)stream, iter, chain0 + n, d) * sc);
+        out[(int64_t)d * ldn + n] = (T)(rng_normal(seed, (uint32_t)stream & 0xFFu, iter, chain0 + n, d,
+                                                   (stream & PBBI_STREAM_DRAW_F64) != 0) * sc);
 }
 
 template <typename T>

@@ -48,16 +48,16 @@ __device__ __forceinline__ void load_rows(const T* col, int64_t ld, int j0, int 
 
 template <typename F>
 __device__ __forceinline__ void draw_rows(uint64_t seed, uint64_t iter, uint64_t chain, int D,
-                                          double pstd, F&& visit) {
+                                          double pstd, bool f64, F&& visit) {
     for (int G = 0; 16 * G < D; ++G) {
-        float z[4][4];
+        double z[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            rng_normal4(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), z[r]);
+            rng_normal4d(seed, PBBI_STREAM_MOMENTUM, iter, chain, (uint32_t)((G << 2) | r), f64, z[r]);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int d = 16 * G + k;
-            if (d < D) visit(d, (T)((double)z[k & 3][k >> 2] * pstd));
+            if (d < D) visit(d, (T)(z[k & 3][k >> 2] * pstd));
         }
     }
 }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
 
     T pp = T(0), u;
     if (prm.rng) {
-        draw_rows(prm.seed, prm.iter, chain, D, pstd, [&](int d, T p) {
+        draw_rows(prm.seed, prm.iter, chain, D, pstd, (prm.flags & PBBI_DRAW_F64) != 0, [&](int d, T p) {
             pp += p * p;
             c.v[(int64_t)d * ld] = UNIT ? p : p / m;
         });
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(SB) k_custom_hmc(HmcPrm prm) {
         }
     }
     if (po && reject && !compat && prm.rng)
-        draw_rows(prm.seed, prm.iter, chain, D, pstd,
+        draw_rows(prm.seed, prm.iter, chain, D, pstd, (prm.flags & PBBI_DRAW_F64) != 0,
                   [&](int d, T p) { po[(int64_t)d * prm.ldn_out] = p; });
     if (prm.ratio_out) prm.ratio_out[n] = ratio;
     if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
@@ -522,12 +522,13 @@ __global__ void __launch_bounds__(RB) k_custom_reg_hmc(HmcPrm prm) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (16 * G + r < RD) {
-                    float z[4];
-                    rng_normal4(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((G << 2) | r), z);
+                    double z[4];
+                    rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((G << 2) | r),
+                                 (prm.flags & PBBI_DRAW_F64) != 0, z);
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl) {
                         const int d = 16 * G + r + 4 * sl;
-                        if (d < RD) v[d] = (T)((double)z[sl] * pstd);
+                        if (d < RD) v[d] = (T)(z[sl] * pstd);
                     }
                 }
             }

@@ -2247,3 +2247,166 @@ np.savez({str(outp)!r}, q=q_num, p=p_num)
     assert res.returncode == 0, res.stderr[-2000:]
     out = np.load(outp)
     assert scaled_err(out["q"], g["q_h0.1"]) <= RTOL_GOLDEN and scaled_err(out["p"], g["p_h0.1"]) <= RTOL_GOLDEN
+
+
+# ---------------------------------------------------------------------------------------------
+# PBBI_DRAW_F64: the double-precision momentum draw of the RNG contract (include/pbbi.h) -- the
+# counterpart of the reference's float64 normals (src/ensemble.py:72-74,88-91).  Built from
+# +, -, *, /, sqrt, fma in a fixed order, so the oracle's restatement gives THE SAME BITS and a
+# whole pbbi_hmc_run can be compared with a host-only oracle run (no device draws replayed).
+# ---------------------------------------------------------------------------------------------
+def ulp_distance(a, b):
+    ia, ib = np.ascontiguousarray(a).view(np.int64), np.ascontiguousarray(b).view(np.int64)
+    ia = np.where(ia < 0, np.int64(-2 ** 63) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-2 ** 63) - ib, ib)
+    return np.abs(ia - ib)
+
+
+def test_f64_draw_device_equals_oracle_mirror(lib):
+    """pbbi_philox_normal with PBBI_STREAM_DRAW_F64 against oracle_philox_normal with the same bit: at most
+    2 ulp apart (the bar); in fact the same bits, scaling included."""
+    D, N = 40, 20000
+    for seed, it, chain0, scale, per_chain in ((77, 3, 123456789012, 1.5, False), (2 ** 63 + 9, 0, 0, 1.0, True)):
+        sn = 0.5 + (np.arange(N) % 7) * 0.25 if per_chain else None
+        z = device_normal(lib, seed, lib.STREAM_MOMENTUM | lib.STREAM_DRAW_F64, it, chain0, D, N, scale, sn)
+        zo = orc.philox_normal(seed, orc.STREAM_MOMENTUM | orc.STREAM_DRAW_F64, it, chain0, D, N,
+                               sn if per_chain else scale)
+        d = ulp_distance(z, zo)
+        assert d.max() <= 2, d.max()
+        assert np.array_equal(z, zo), f"{(d > 0).mean():.2e} of the variates differ by <= {d.max()} ulp"
+    # position stream, float32 output: the double variate rounded once
+    from physicsbasedbayesianinference_amd._device import empty, stream_ptr, to_numpy
+    out = empty((D, 500), np.float32, 0)
+    lib.call("pbbi_philox_normal", 5, lib.STREAM_POSITION | lib.STREAM_DRAW_F64, 1, 7, D, 500, 500, 2.0, None,
+             lib.F32, 0, out.data_ptr(), stream_ptr(0))
+    zo = orc.philox_normal(5, orc.STREAM_POSITION | orc.STREAM_DRAW_F64, 1, 7, D, 500, 2.0)
+    assert np.array_equal(to_numpy(out), zo.astype(np.float32))
+
+
+def test_f64_draw_distribution(lib):
+    """N(0,1): moments, KS on 2.6e6 variates (all of them, the grid is 2^-52), independence inside and across
+    blocks, no ties, sharding by chain offset."""
+    from scipy import stats
+    z = device_normal(lib, 5, lib.STREAM_MOMENTUM | lib.STREAM_DRAW_F64, 0, 0, 128, 20000)
+    assert abs(z.mean()) < 3e-3 and abs(z.std() - 1) < 2e-3
+    assert abs(stats.skew(z.ravel())) < 0.01 and abs(stats.kurtosis(z.ravel())) < 0.02
+    assert stats.kstest(z.ravel(), "norm").pvalue > 1e-3
+    assert np.abs(z).max() > 4.5
+    c = np.corrcoef(z[:32])
+    assert np.max(np.abs(c - np.eye(32))) < 0.04
+    assert np.unique(z).size == z.size
+    zs = device_normal(lib, 5, lib.STREAM_MOMENTUM | lib.STREAM_DRAW_F64, 0, 3000, 128, 500)
+    assert np.array_equal(zs, z[:, 3000:3500])
+    assert not np.array_equal(z[:, :500], device_normal(lib, 5, lib.STREAM_MOMENTUM, 0, 0, 128, 500))
+
+
+F64_RUNS = [
+    # name, kind, D, N, flags (beyond compat | DRAW_F64), dtype, tolerance (None = bit-exact), mass
+    ("lane_diag8", "diag", 8, 300, 0, "float64", None, True),
+    ("lane2_ros32_exact", "ros", 32, 200, 0, "float64", None, False),
+    ("lane2_ros32_kdk", "ros", 32, 200, "kdk", "float64", 1e-12, False),
+    ("lane2_ros24_kdk_mass", "ros", 24, 130, "kdk", "float64", 1e-12, True),
+    ("sepx_diag64_exact", "diag", 64, 200, 0, "float64", None, True),
+    ("sepn_diag64_kdk", "diag", 64, 200, "kdk", "float64", 1e-12, False),
+    ("rosgx_ros64_exact", "ros", 64, 130, 0, "float64", None, False),
+    ("rosg_ros64_kdk", "ros", 64, 130, "kdk", "float64", 1e-12, True),
+    ("rosn_ros200_kdk", "ros", 200, 70, "kdk", "float64", 1e-12, False),
+    ("stream_ros300", "ros", 300, 70, 0, "float64", None, True),
+    ("stream_diag12_f32", "diag", 12, 200, 0, "float32", 3e-5, False),
+    ("dense128_fused", "dense", 128, 300, 0, "float64", 1e-11, False),
+    ("dense128_mass", "dense", 128, 150, 0, "float64", 1e-11, True),
+    ("dense100", "dense", 100, 150, 0, "float64", 1e-11, False),
+    ("dense24", "dense", 24, 70, 0, "float64", 1e-11, True),
+    ("gemm_dense200", "dense", 200, 150, 0, "float64", 1e-10, False),
+    ("gemm_dense256_f32", "dense", 256, 128, 0, "float32", 2e-4, False),
+    ("custom_quartic9", "quartic", 9, 300, 0, "float64", None, True),
+    ("custom_quartic48", "quartic", 48, 100, 0, "float64", None, False),
+]
+
+
+@pytest.mark.parametrize("name,kind,D,N,extra,dtype,tol,mass", F64_RUNS, ids=[r[0] for r in F64_RUNS])
+def test_hmc_run_with_f64_draws_vs_host_only_oracle(P, lib, name, kind, D, N, extra, dtype, tol, mass):
+    """pbbi_hmc_run with PBBI_DRAW_F64 in every kernel family against oracle_hmc_run_philox with the same flag,
+    which draws ITS OWN momenta (the oracle's C restatement of the draw): decisions equal, states bit-exact
+    where the kernel keeps the reference's operation order, within the family's tolerance elsewhere."""
+    import torch
+    from custom_sources import QUARTIC
+    from physicsbasedbayesianinference_amd.custom import CustomPotential
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D)
+    S, L, h = 5, 6, 0.1
+    if kind == "diag":
+        mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2, D)
+        pot, op = P.GaussianDiag(mu, prec=prec, const=0.0, dtype=dtype), orc.pot_gauss_diag(mu, prec)
+    elif kind == "ros":
+        pot, op, h = P.Rosenbrock(D, dtype=dtype), orc.pot_rosenbrock(D), 0.01
+    elif kind == "dense":
+        A = rs.standard_normal((D, D))
+        Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+        Pm = 0.5 * (Pm + Pm.T)
+        pot, op = P.GaussianDense(None, precision=Pm, const=0.0, dtype=dtype), orc.pot_gauss_dense(np.zeros(D), Pm)
+    else:
+        pot, op, h = CustomPotential(D, QUARTIC, [1.0, 0.5]), orc.pot_custom(QUARTIC, D, [1.0, 0.5]), 0.2
+    npdt = np.float32 if dtype == "float32" else np.float64
+    m = (1.0 + (np.arange(N) % 3) * 0.5) if mass else None
+    md = as_device(m, 0, npdt) if mass else None
+    seed, iter0, chain0, kT = 99, 3, 2 ** 32 + 11, 1.0
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.DRAW_F64 | (lib.KDK_FMA if extra == "kdk" else 0)
+    q0 = orc.philox_normal(seed, orc.STREAM_POSITION | orc.STREAM_DRAW_F64, iter0, chain0, D, N,
+                           0.1 if kind == "ros" else 1.0) + (1.0 if kind == "ros" else 0.0)
+    if dtype == "float32":
+        q0 = q0.astype(np.float32).astype(np.float64)
+    qd = as_device(q0, 0, npdt)
+    samples, momenta = empty((S, D, N), npdt, 0), empty((S, D, N), npdt, 0)
+    reject = empty((S, N), np.uint8, 0)
+    lib.call("pbbi_hmc_run", pot.handle, lib.LEAPFROG, qd.data_ptr(), md.data_ptr() if mass else None,
+             samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, S, flags, seed, iter0,
+             chain0, kT, stream_ptr(0))
+    torch.cuda.synchronize()
+    gs, gm, gr = (to_numpy(x) for x in (samples, momenta, reject))
+    q = np.ascontiguousarray(q0)
+    if dtype == "float64":
+        os_, om, orj, _ = orc.hmc_run_philox(op, "Leapfrog", q, m, h, L, S, seed, iter0, chain0, kT,
+                                            compat=orc.COMPAT_P_FROM_OLDQ | orc.DRAW_F64)
+        assert np.array_equal(gr.astype(bool), orj)
+        if tol is None:
+            assert np.array_equal(gs, os_) and np.array_equal(gm, om)
+        else:
+            assert scaled_err(gs, os_) <= tol and scaled_err(gm, om) <= tol
+    else:  # float32 kernels against the fp64 oracle restarted from the kernel's own state every iteration
+        pstd = np.sqrt((m if mass else np.ones(N)) * kT)
+        for i in range(S):
+            p = (orc.philox_normal(seed, orc.STREAM_MOMENTUM | orc.STREAM_DRAW_F64, iter0 + i, chain0, D, N, pstd)
+                 ).astype(np.float32).astype(np.float64)
+            u = orc.philox_uniform(seed, iter0 + i, chain0, N)
+            p = np.ascontiguousarray(p)
+            ratio, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, m, h, L)
+            with np.errstate(divide="ignore"):
+                clear = np.abs(np.log(u) - np.minimum(0.0, np.log(ratio))) > 1e-2
+            assert np.array_equal(gr[i].astype(bool)[clear], rej[clear])
+            same = gr[i].astype(bool) == rej
+            assert scaled_err(gs[i][:, same], q[:, same]) <= tol and scaled_err(gm[i][:, same], p[:, same]) <= tol
+            q = np.ascontiguousarray(gs[i].astype(np.float64))
+    assert 0.0 <= gr.mean() < 0.9
+
+
+def test_class_api_draw_f64(P, lib):
+    """HMC(..., rng="philox", draw_f64=True): positions and momenta from the double-precision draw; equal to a
+    host-only oracle run; the default (single precision) gives a different, equally valid run."""
+    D, N, S, L, h, seed = 6, 500, 4, 5, 0.2, 21
+    rs = np.random.RandomState(0)
+    mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2, D)
+    pot, op = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec)
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=False, draw_f64=True,
+                verbose=False)
+    s, mom = hmc.getSamples(S, 1.0 / kB, 0.7)
+    q = np.ascontiguousarray(orc.philox_normal(seed, orc.STREAM_POSITION | orc.STREAM_DRAW_F64, 0, 0, D, N, 0.7))
+    os_, om, orj, _ = orc.hmc_run_philox(op, "Leapfrog", q, None, h, L, S, seed, 0, 0, 1.0,
+                                        compat=orc.COMPAT_P_FROM_OLDQ | orc.DRAW_F64)
+    assert np.array_equal(hmc.reject_masks, orj)
+    assert np.array_equal(s, os_.transpose(1, 2, 0)) and np.array_equal(mom, om.transpose(1, 2, 0))
+    hmc32 = P.HMC(P.Ensemble(D, N), L * h + 1e-9, h, None, potential=pot, rng="philox", seed=seed, kdk_fma=False,
+                  verbose=False)
+    s32, _ = hmc32.getSamples(S, 1.0 / kB, 0.7)
+    assert not np.array_equal(s32, s)

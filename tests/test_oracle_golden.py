@@ -239,3 +239,58 @@ def test_philox_run_matches_iter_composition():
         assert np.array_equal(samples[i], q2) and np.array_equal(momenta[i], p)
         assert np.array_equal(rej[i], rej2)
     assert np.array_equal(q, q2)
+
+
+# ---- the double-precision draw of the RNG contract (PBBI_DRAW_F64, include/pbbi.h) -------------------
+def test_f64_draw_matches_the_contract_step_by_step():
+    """oracle_philox_normal with the PBBI_STREAM_DRAW_F64 bit against a step-by-step Python statement of the
+    contract (tools/gen_draw_coeffs.py: exact rational fma, the same operation order): the same bits."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "gen_draw_coeffs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                        "gen_draw_coeffs.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    seed, it, D = 0x1234567890ABCDEF, 7, 40
+    for chain0, N in ((0, 6), (2 ** 33 + 5, 3)):
+        z = orc.philox_normal(seed, orc.STREAM_MOMENTUM | orc.STREAM_DRAW_F64, it, chain0, D, N)
+        for n in range(N):
+            chain = chain0 + n
+            for d in range(D):
+                slot = (d >> 2) & 3
+                blk = (((d >> 4) << 2) | (d & 3)) | (0x80000000 if slot >= 2 else 0)
+                x = orc.philox_raw([chain & 0xFFFFFFFF, blk, it, orc.STREAM_MOMENTUM | ((chain >> 32) << 8)],
+                                   [seed & 0xFFFFFFFF, seed >> 32])
+                assert G.box_muller(x)[slot & 1] == z[d, n], (d, n)
+
+
+def test_f64_draw_is_standard_normal_with_long_tails():
+    from scipy import stats
+    z = orc.philox_normal(11, orc.STREAM_MOMENTUM | orc.STREAM_DRAW_F64, 0, 0, 64, 32768).ravel()   # 2.1e6 variates
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1.0) < 3e-3
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    assert abs(stats.skew(z)) < 0.01 and abs(stats.kurtosis(z)) < 0.02
+    # pairs from one block are uncorrelated; dims of different blocks too
+    zz = z.reshape(64, 32768)
+    assert abs(np.corrcoef(zz[0], zz[4])[0, 1]) < 0.02 and abs(np.corrcoef(zz[0], zz[8])[0, 1]) < 0.02
+    # not the single-precision draw, and finer than its 2^-24 grid
+    zf = orc.philox_normal(11, orc.STREAM_MOMENTUM, 0, 0, 64, 32768).ravel()
+    assert abs(np.corrcoef(z, zf)[0, 1]) < 0.01
+    assert np.unique(z).size == z.size
+
+
+def test_f64_draw_tail_reach():
+    """The smallest radius argument (w1 >> 12 == 0, u1 = 2^-53) gives r = sqrt(106 ln 2) = 8.57 sigma: the tails
+    the single-precision draw cuts at 6.7 sigma are there."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "gen_draw_coeffs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                        "gen_draw_coeffs.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    zc, zs = G.box_muller([0, 0, 0, 0])
+    assert abs(zc - np.sqrt(106 * np.log(2.0))) < 1e-14 and zs == 0.0
+    zc, zs = G.box_muller([0xFFF, 0, 0, 0x40000000])      # still u1 = 2^-53; angle pi/2
+    assert abs(zs - np.sqrt(106 * np.log(2.0))) < 1e-14 and abs(zc) < 1e-15
