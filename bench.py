@@ -16,8 +16,9 @@ reference's getSamples loop (src/HMC.py:154-179): momentum draw (in-kernel Philo
 L leapfrog steps with L+1 gradient evaluations, both Hamiltonians, Metropolis
 accept/reject, and the store of the position AND momentum sample slabs.  Inputs are
 resident in HBM when the timed region starts.  With N > 1 every rank owns its own 65 536
-chains (weak scaling, C4 = 8 x 65 536); the only collective is the RCCL all-gather of the
-final sample slab AFTER the timed region (reported as allgather_ms).
+chains (weak scaling, C4 = 8 x 65 536); the only collective is the RCCL all-gather of sample
+slabs, measured AFTER the timed region: blocking (allgather_ms, bytes, GB/s) and overlapped with the
+sampling of the next chunk (collection.overlapped: the exposed time).
 
 value = K * L * N_total_chains / t, t = max over ranks of the barrier-bracketed wall time of
 the K steps that follow EXACTLY W warm-up steps.  `value_steady` is the same measurement repeated
@@ -397,7 +398,6 @@ def bench_c2(args, rank, world, local_rank):
     import torch.distributed as dist
     import physicsbasedbayesianinference_amd as P
     from physicsbasedbayesianinference_amd import _lib
-    from physicsbasedbayesianinference_amd.distributed import gather_samples
 
     _lib.load()  # raises if the HIP extension is missing: no fallback
     dev = local_rank
@@ -442,16 +442,52 @@ def bench_c2(args, rank, world, local_rank):
     (t, dev_ms), (ts, dev_ms_s) = timed_runs(run, K, W, SETTLE, barrier, reduce_max)
     accept = 1.0 - float(reject[:K].float().mean().item())
 
-    # sample collection: ONE all-gather of the last slab over RCCL/xGMI, outside the timed loop
-    allgather_ms = None
+    # sample collection (outside the timed loop): (1) ONE blocking all-gather of a chunk of slabs over
+    # RCCL/xGMI, received in place; (2) the same chunks collected WHILE the next chunk samples
+    # (distributed.OverlappedGather: side stream, two send / two receive buffers) against the same sampling
+    # without any collection -- the difference is what the collection costs when it is overlapped
+    collect = None
     if world > 1:
+        from physicsbasedbayesianinference_amd.distributed import OverlappedGather, gather_blocks
+        c = max(1, min(K, 8))                       # slabs per chunk: 8 x 64 MiB per rank at C2
+        n_chunks = 4
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        full = gather_samples(samples[K - 1:K])
+        blk = gather_blocks(samples[:c], n_total=N * world)
         torch.cuda.synchronize()
-        allgather_ms = (time.perf_counter() - g0) * 1e3
-        assert full.shape == (1, D, N * world)
+        allgather_s = time.perf_counter() - g0
+        assert blk.blocks.shape == (world, c, D, N)
+        gathered_bytes = blk.blocks.numel() * 8
+        del blk
+
+        def chunks(og):
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(n_chunks):
+                buf = og.local(k) if og is not None else samples[(k & 1) * c:(k & 1) * c + c]
+                _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q_state.data_ptr(), None, buf.data_ptr(),
+                          None, reject.data_ptr(), None, N, N, STEP, L, c, run_flags, seed, 10 ** 6 + k * c,
+                          chain0, 1.0, stream)
+                if og is not None:
+                    og.submit(k, c)
+            if og is not None:
+                og.finish()
+            torch.cuda.synchronize()
+            barrier()
+            return reduce_max(time.perf_counter() - t0)
+        og = OverlappedGather((c, D, N), torch.float64, f"cuda:{dev}", N * world)
+        chunks(og)                                   # (first use: communicator / buffer warm-up)
+        t_over = chunks(og)
+        t_plain = chunks(None)
+        collect = {"allgather_ms": allgather_s * 1e3, "allgather_bytes_received_per_rank": gathered_bytes,
+                   "allgather_GBs_per_rank": gathered_bytes / allgather_s / 1e9,
+                   "overlapped": {"chunks": n_chunks, "iterations_per_chunk": c,
+                                  "sampling_only_ms": t_plain * 1e3, "sampling_with_overlapped_gather_ms": t_over * 1e3,
+                                  "exposed_collection_ms": (t_over - t_plain) * 1e3,
+                                  "note": "chunk k's all_gather_into_tensor runs on a side stream while chunk k+1 "
+                                          "samples; received in place into (world, c, D, N) blocks"}}
     if rank != 0:
         return None
     total_chains = N * world
@@ -510,8 +546,9 @@ def bench_c2(args, rank, world, local_rank):
             hbm_required_GBs=bytes_exec / kernel_s / 1e9,
             hbm_frac_of_8TBs=bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS),
     }
-    if allgather_ms is not None:
-        out["allgather_ms"] = allgather_ms
+    if collect is not None:
+        out["allgather_ms"] = collect["allgather_ms"]
+        out["collection"] = collect
     del samples, momenta, reject
     torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:

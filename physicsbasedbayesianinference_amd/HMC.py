@@ -328,6 +328,65 @@ class HMC:
         print("time step: ", self.stepSize)
 
     # ------------------------------------------------------------------ sampling
+    def _numpy_stream_run(self, S, temperature, qStd, host_stream=None):
+        """rng="numpy" plumbing shared by getSamples and sampleChunksGathered: identical RNG consumption to the
+        reference -- q0 (src/HMC.py:148), then per iteration p (src/ensemble.py:88-91, src/HMC.py:154) and u
+        (src/HMC.py:168) -- drawn by the host pipeline (one producer thread, pinned staging, side-stream
+        upload) and consumed by one pbbi_hmc_iter_kt launch per iteration."""
+        pot, ens = self._pot, self.ensemble
+        D, N = ens.numDimensions, ens.numParticles
+        dev, dt = pot.device, pot.dtype
+        if host_stream is None:
+            self.integrator.q = ens.setPosition(qStd)                   # :148
+        else:
+            self.integrator.q = ens.q = host_stream.positions(qStd)
+        hmc = self
+
+        class Run:
+            pass
+        run = Run()
+        run.q0 = as_device(self.integrator.q, dev, dt)
+        kT_host = float(boltzmannConst * temperature) if self.beta_accept else 1.0
+
+        def draw(i, pin_p=None, pin_u=None):
+            """Iteration i's draws in the reference's order (p, then u).  With float64 upload buffers
+            (pin_p, pin_u: NumPy views of pinned memory) they are written there directly."""
+            if hmc.verbose and i % 100 == 0:
+                print("HMC iteration ", i + 1)                           # :151-152
+            if host_stream is None and pin_p is not None:
+                pStd = np.sqrt(ens.mass * boltzmannConst * temperature)  # src/ensemble.py:88
+                p = ens.p = _hoststream.scaled_normal_into(pin_p, pStd)  # :89-91, :154
+                u = _hoststream.uniform_into(pin_u)                      # :168
+            elif host_stream is None:
+                p = ens.setMomentum(temperature)                         # :154
+                u = _hoststream.uniform(N)                               # :168 (np.random.uniform(size=N))
+            else:
+                p = ens.p = host_stream.momenta(ens.mass, temperature)
+                u = host_stream.uniforms()
+                if pin_p is not None:
+                    pin_p[...], pin_u[...] = p, u
+            hmc.integrator.p = p
+            return p, u
+        # The NumPy legacy stream can only be drawn in order, on the host (~15 ns per normal):
+        # a producer thread draws iteration i+1 into pinned memory and starts its upload on a
+        # side stream while iteration i's kernel runs (_HostDrawPipeline above).
+        run.pipe = _HostDrawPipeline(draw, S, D, N, dev, dt)
+        md = self._mass()
+        mptr = md.data_ptr() if md is not None else None
+        L, h, flags, stream = self.integrator.numSteps, float(self.stepSize), self._flags(), stream_ptr(dev)
+
+        def step(i, q_in, q_out, p_out, ratio_out, reject_out):
+            slot = run.pipe.acquire()
+            _lib.call("pbbi_hmc_iter_kt", pot.handle, hmc.integrator.method_id, q_in.data_ptr(),
+                      slot.p.data_ptr(), slot.u.data_ptr(), mptr, q_out.data_ptr(),
+                      p_out.data_ptr() if p_out is not None else None,
+                      ratio_out.data_ptr() if ratio_out is not None else None,
+                      reject_out.data_ptr() if reject_out is not None else None, N, N, h, L, flags, kT_host,
+                      stream)
+            run.pipe.release(slot)
+        run.step, run.keep = step, md
+        return run
+
     def getSamples(self, numSamples, temperature, qStd, rng=None, seed=None, device_output=False,
                    chain0=0, iter0=0, host_stream=None, jitter=0.0, burn_in=0, per_chain_steps=False):
         """HMC.getSamples (src/HMC.py:123-183): returns (samples_hmc, momentum_hmc), each
@@ -377,49 +436,16 @@ class HMC:
                              "the reference's stream)")
         self.steps = None
         if rng == "numpy":
-            # identical RNG consumption to the reference: q0, then per iteration p then u
-            if host_stream is None:
-                self.integrator.q = ens.setPosition(qStd)                   # :148
-            else:
-                self.integrator.q = ens.q = host_stream.positions(qStd)
-            q_prev = as_device(self.integrator.q, dev, dt)
-            kT_host = float(boltzmannConst * temperature) if self.beta_accept else 1.0
-
-            def draw(i, pin_p=None, pin_u=None):
-                """Iteration i's draws in the reference's order (p, then u).  With float64 upload buffers
-                (pin_p, pin_u: NumPy views of pinned memory) they are written there directly."""
-                if self.verbose and i % 100 == 0:
-                    print("HMC iteration ", i + 1)                           # :151-152
-                if host_stream is None and pin_p is not None:
-                    pStd = np.sqrt(ens.mass * boltzmannConst * temperature)  # src/ensemble.py:88
-                    p = ens.p = _hoststream.scaled_normal_into(pin_p, pStd)  # :89-91, :154
-                    u = _hoststream.uniform_into(pin_u)                      # :168
-                elif host_stream is None:
-                    p = ens.setMomentum(temperature)                         # :154
-                    u = _hoststream.uniform(N)                               # :168 (np.random.uniform(size=N))
-                else:
-                    p = ens.p = host_stream.momenta(ens.mass, temperature)
-                    u = host_stream.uniforms()
-                    if pin_p is not None:
-                        pin_p[...], pin_u[...] = p, u
-                self.integrator.p = p
-                return p, u
-            # The NumPy legacy stream can only be drawn in order, on the host (~15 ns per normal):
-            # a producer thread draws iteration i+1 into pinned memory and starts its upload on a
-            # side stream while iteration i's kernel runs (_HostDrawPipeline below).
-            pipe = _HostDrawPipeline(draw, S, D, N, dev, dt)
+            run = self._numpy_stream_run(S, temperature, qStd, host_stream)
+            q_prev = run.q0
             try:
                 for i in range(S):
-                    slot = pipe.acquire()
-                    _lib.call("pbbi_hmc_iter_kt", pot.handle, self.integrator.method_id,
-                              q_prev.data_ptr(), slot.p.data_ptr(), slot.u.data_ptr(), mptr,
-                              samples[i].data_ptr(), momenta[i].data_ptr(), ratio[i].data_ptr(),
-                              reject[i].data_ptr(), N, N, h, L, flags, kT_host, stream)
-                    pipe.release(slot)
+                    run.step(i, q_prev, samples[i], momenta[i], ratio[i], reject[i])
                     q_prev = samples[i]
-                pipe.finished = True  # every iteration was launched: the staging buffers may be kept
+                run.pipe.finished = True  # every iteration was launched: the staging buffers may be kept
             finally:
-                pipe.close()
+                run.pipe.close()
+            pipe = run.pipe
             self.host_rng_ms = pipe.draw_seconds * 1e3 / max(S, 1)
         elif rng == "philox":
             kT = float(boltzmannConst * temperature)                         # src/ensemble.py:88
@@ -526,6 +552,74 @@ class HMC:
             k += 1
             self.acceptRate = 1.0 - n_rej / (done * N) if N else None
             yield s_view, m_view
+
+    def sampleChunksGathered(self, numSamples, chunk, temperature, qStd, n_total=None, seed=None, chain0=0, iter0=0,
+                             host_stream=None, momenta=False, group=None, rng=None):
+        """sampleChunks for a SHARDED ensemble with the collection overlapped (driven by
+        distributed.sample_chunks_sharded): this rank's chains are sampled in chunks of `chunk` iterations and
+        chunk k's all-gather runs on a side stream while chunk k+1 samples (distributed.OverlappedGather: two
+        send and two receive buffers, received in place).  Yields (samples GatheredBlocks, momenta
+        GatheredBlocks | None, self) per chunk; a chunk's buffers are overwritten two chunks later.  Both RNG
+        modes: "philox" (one pbbi_hmc_run per chunk, global chain index chain0 + n in the counters) and "numpy"
+        (the global NumPy stream replayed, this shard's columns kept: host_stream)."""
+        from .distributed import OverlappedGather
+        from ._device import torch_dtype
+        pot, ens = self._pot, self.ensemble
+        D, N = ens.numDimensions, ens.numParticles
+        S, chunk = int(numSamples), max(1, int(chunk))
+        rng = self.rng if rng is None else rng
+        seed = self.seed if seed is None else int(seed)
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+        n_total = N if n_total is None else int(n_total)
+        c_alloc = min(chunk, max(S, 1))
+        tdev = f"cuda:{dev}"
+        og_s = OverlappedGather((c_alloc, D, N), torch_dtype(dt), tdev, n_total, group)
+        og_m = OverlappedGather((c_alloc, D, N), torch_dtype(dt), tdev, n_total, group) if momenta else None
+        reject = empty((c_alloc, N), np.uint8, dev)
+        md = self._mass()
+        mptr = md.data_ptr() if md is not None else None
+        if rng == "philox":
+            kT = float(boltzmannConst * temperature)
+            q_state = empty((D, N), dt, dev)
+            _lib.call("pbbi_philox_normal", seed, self._position_stream(), int(iter0), int(chain0), D, N, N,
+                      float(qStd), None, pot._dt, dev, q_state.data_ptr(), stream)
+            run = None
+        elif rng == "numpy":
+            run = self._numpy_stream_run(S, temperature, qStd, host_stream)
+            q_prev = run.q0
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        done, k, n_rej = 0, 0, 0.0
+        try:
+            while done < S:
+                c = min(chunk, S - done)
+                sbuf = og_s.local(k)
+                mbuf = og_m.local(k) if momenta else None
+                if run is None:
+                    _lib.call("pbbi_hmc_run", pot.handle, self.integrator.method_id, q_state.data_ptr(), mptr,
+                              sbuf.data_ptr(), mbuf.data_ptr() if momenta else None, reject.data_ptr(), None, N, N,
+                              float(self.stepSize), self.integrator.numSteps, c, self._flags(), seed,
+                              int(iter0) + done, int(chain0), kT, stream)
+                else:
+                    for i in range(c):
+                        run.step(done + i, q_prev, sbuf[i], mbuf[i] if momenta else None, None, reject[i])
+                        q_prev = sbuf[i]
+                n_rej += float(reject[:c].float().sum().item()) if N else 0.0
+                got_s = og_s.submit(k, c)
+                got_m = og_m.submit(k, c) if momenta else None
+                done += c
+                k += 1
+                self.acceptRate = 1.0 - n_rej / (done * N) if N else None
+                if got_s is not None:
+                    yield got_s, got_m, self
+            if run is not None:
+                run.pipe.finished = True
+        finally:
+            if run is not None:
+                run.pipe.close()
+        if S > 0:
+            yield og_s.finish(), (og_m.finish() if momenta else None), self
 
     def adaptStepSize(self, temperature, qStd, target=0.8, iterations=60, seed=None, chain0=0,
                       gamma=0.05, t0=10.0, kappa=0.75):

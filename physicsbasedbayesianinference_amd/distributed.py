@@ -19,7 +19,8 @@ from scipy.constants import k as boltzmannConst
 
 from . import _hoststream
 
-__all__ = ["ensemble_weights", "shard_bounds", "HostStream", "gather_samples", "get_samples_sharded"]
+__all__ = ["ensemble_weights", "shard_bounds", "HostStream", "gather_samples", "gather_blocks", "GatheredBlocks",
+           "OverlappedGather", "get_samples_sharded", "sample_chunks_sharded"]
 
 
 def shard_bounds(numParticles, rank, world):
@@ -62,11 +63,95 @@ def _dist():
     return dist
 
 
-def gather_samples(local_sdn, group=None, _force_collective=False):
-    """All-gather per-rank (S, D, N_local) slabs along the chain axis -> (S, D, N_total) on
-    every rank (rank r's chains at columns shard_bounds(N_total, r, world)).  One collective:
-    `all_gather_into_tensor` when the shards are equal, a padded one otherwise.  Works on CUDA
-    tensors over RCCL and on CPU tensors over gloo."""
+def _shard_sizes(n_total, world):
+    return [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
+
+
+class GatheredBlocks:
+    """What an all-gather of (S, D, N_local) slabs lands in: ONE buffer `blocks` of shape
+    (world, S, D, N_max) -- rank r's slabs at blocks[r] (columns past sizes[r] are padding when the split is
+    uneven) -- received IN PLACE by `all_gather_into_tensor`, nothing copied afterwards.  Views:
+      view4()   (S, D, world, N_max): permuted view, chain (r, n) = global chain offsets[r] + n
+      rank(r)   (S, D, sizes[r]) view of rank r's block
+      to_sdn()  (S, D, N_total) contiguous COPY (the chain axis is not contiguous in `blocks`)
+    A reduction over all draws of all chains (pbbi_sample_moments & co.) can read `blocks` itself as
+    (world*S, D, N_max) slabs when the split is even."""
+
+    def __init__(self, blocks, sizes):
+        self.blocks, self.sizes = blocks, list(sizes)
+        self.offsets = [0]
+        for n in self.sizes[:-1]:
+            self.offsets.append(self.offsets[-1] + n)
+        self.n_total = sum(self.sizes)
+
+    @property
+    def even(self):
+        return all(n == self.sizes[0] for n in self.sizes)
+
+    def view4(self):
+        return self.blocks.permute(1, 2, 0, 3)
+
+    def rank(self, r):
+        return self.blocks[r, :, :, :self.sizes[r]]
+
+    def to_sdn(self, out=None):
+        import torch
+        world, S, D, _ = self.blocks.shape
+        if out is None:
+            out = torch.empty((S, D, self.n_total), dtype=self.blocks.dtype, device=self.blocks.device)
+        for r in range(world):
+            out[:, :, self.offsets[r]:self.offsets[r] + self.sizes[r]] = self.rank(r)
+        return out
+
+
+def gather_blocks(local_sdn, n_total=None, group=None, out=None, async_op=False, _force_collective=False):
+    """ONE all-gather of per-rank (S, D, N_local) slabs, received in place into a (world, S, D, N_max)
+    buffer (`out` reuses a caller-owned one) -> GatheredBlocks (no copy, no host synchronisation).
+    `n_total`: chains of the whole ensemble, sharded by `shard_bounds` -- the shard sizes then follow
+    without an exchange; None asks the ranks (one small all_gather and a host sync).
+    async_op=True returns (GatheredBlocks, work): the collective is in flight until work.wait()."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    S, D, Nl = local_sdn.shape
+    if n_total is not None:
+        sizes = _shard_sizes(int(n_total), world)
+        rank = dist.get_rank(group) if world > 1 else 0
+        if sizes[rank] != Nl:
+            raise ValueError(f"rank {rank} holds {Nl} chains, shard_bounds({n_total}, {rank}, {world}) says {sizes[rank]}")
+    elif world == 1:
+        sizes = [Nl]
+    else:
+        mine = torch.tensor([Nl], dtype=torch.int64, device=local_sdn.device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        sizes = [int(x.item()) for x in every]
+    Nmax = max(sizes)
+    send = local_sdn.contiguous()
+    if Nl != Nmax:  # uneven split: the send buffer is padded to the largest shard
+        pad = torch.zeros((S, D, Nmax), dtype=send.dtype, device=send.device)
+        pad[:, :, :Nl] = send
+        send = pad
+    if out is None:
+        out = torch.empty((world, S, D, Nmax), dtype=send.dtype, device=send.device)
+    elif tuple(out.shape) != (world, S, D, Nmax) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous ({world}, {S}, {D}, {Nmax}) buffer")
+    work = None
+    if world == 1 and not _force_collective:
+        out[0].copy_(send)
+    else:
+        work = dist.all_gather_into_tensor(out.view(world * S, D, Nmax), send, group=group, async_op=async_op)
+    res = GatheredBlocks(out, sizes)
+    return (res, work) if async_op else res
+
+
+def gather_samples(local_sdn, group=None, _force_collective=False, n_total=None, max_chunk_bytes=1 << 28):
+    """All-gather per-rank (S, D, N_local) slabs along the chain axis -> a contiguous (S, D, N_total) tensor on
+    every rank (rank r's chains at columns shard_bounds(N_total, r, world)).  The chain axis of the result
+    is not contiguous in what a collective delivers (rank-major blocks), so the blocks are re-laid: to keep
+    the peak at ~1x the result the slabs travel in groups of <= max_chunk_bytes per rank, each received in
+    place and copied into its columns (`gather_blocks` returns the received blocks themselves, with no
+    copy at all).  Works on CUDA tensors over RCCL and on CPU tensors over gloo."""
     import torch
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()):
@@ -75,22 +160,143 @@ def gather_samples(local_sdn, group=None, _force_collective=False):
     if world == 1 and not _force_collective:  # (_force_collective: the one-rank RCCL test on a one-GPU box)
         return local_sdn
     S, D, Nl = local_sdn.shape
-    sizes = torch.tensor([Nl], dtype=torch.int64, device=local_sdn.device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    all_sizes = [int(s.item()) for s in all_sizes]
-    Nmax = max(all_sizes)
-    send = local_sdn.contiguous()
-    if Nl != Nmax:  # uneven split: pad to the largest shard, trim after the gather
-        pad = torch.zeros((S, D, Nmax), dtype=send.dtype, device=send.device)
-        pad[:, :, :Nl] = send
-        send = pad
-    flat = torch.empty((world * S, D, Nmax), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(flat, send, group=group)  # rank r's slab at rows [r*S, (r+1)*S)
-    recv = flat.view(world, S, D, Nmax)
-    if all(n == Nmax for n in all_sizes):
-        return recv.permute(1, 2, 0, 3).reshape(S, D, world * Nmax)
-    return torch.cat([recv[r, :, :, :all_sizes[r]] for r in range(world)], dim=2)
+    first = gather_blocks(local_sdn[:0], n_total, group, _force_collective=_force_collective) if n_total is None else None
+    sizes = first.sizes if first is not None else _shard_sizes(int(n_total), world)
+    N = sum(sizes)
+    out = torch.empty((S, D, N), dtype=local_sdn.dtype, device=local_sdn.device)
+    slab_bytes = max(1, D * max(sizes) * local_sdn.element_size())
+    step = max(1, min(S, max_chunk_bytes // slab_bytes)) if S else 1
+    buf = None
+    for s0 in range(0, S, step):
+        c = min(step, S - s0)
+        if buf is None or buf.shape[1] != c:
+            buf = torch.empty((world, c, D, max(sizes)), dtype=local_sdn.dtype, device=local_sdn.device)
+        blk = gather_blocks(local_sdn[s0:s0 + c], N, group, out=buf, _force_collective=_force_collective)
+        blk.to_sdn(out[s0:s0 + c])
+    return out
+
+
+class OverlappedGather:
+    """Collection of a long sharded run off the sampling critical path ("per large chunk,
+    double-buffered"): chunk k's all-gather is in flight on a side stream while chunk k+1 samples.
+
+        og = OverlappedGather((c, D, N_local), dtype, device, n_total)
+        for k in range(n_chunks):
+            buf = og.local(k)              # this rank's (c, D, N_local) slab buffer for chunk k (two alternate)
+            <enqueue the sampling of chunk k into buf[:rows]>
+            done = og.submit(k, rows)      # starts chunk k's gather; returns chunk k-1's GatheredBlocks (or None)
+            if done: consume(done)         # valid until the submit after next
+        consume(og.finish())               # the last chunk
+
+    Two send and two receive buffers.  On CUDA tensors the gather of chunk k is ordered after the sampling of
+    chunk k by an event and runs beside chunk k+1's kernels; the sampling stream waits for chunk k-1's gather
+    only when it hands that chunk out.  On CPU tensors (gloo tests) it is the same protocol with async_op."""
+
+    def __init__(self, shape_local, dtype, device, n_total, group=None):
+        import torch
+        dist = _dist()
+        self.t, self.group = torch, group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        c, D, Nl = shape_local
+        self.sizes = _shard_sizes(int(n_total), self.world)
+        if self.sizes[self.rank] != Nl:
+            raise ValueError("shape_local does not match shard_bounds(n_total, rank, world)")
+        Nmax = max(self.sizes)
+        dev = torch.device(device)
+        self.cuda = dev.type == "cuda"
+        # an uneven split sends padded slabs: the local buffers are allocated at N_max and handed out as
+        # [:, :, :N_local] views -- but a kernel wants dense (D, N_local) slabs, so the padded send buffer is
+        # separate in that case (one extra copy per chunk on the ranks with the short shard only)
+        self.pad = Nl != Nmax
+        self.send = [torch.empty((c, D, Nl), dtype=dtype, device=dev) for _ in range(2)]
+        self.sendpad = [torch.zeros((c, D, Nmax), dtype=dtype, device=dev) for _ in range(2)] if self.pad else None
+        self.recv = [torch.empty((self.world, c, D, Nmax), dtype=dtype, device=dev) for _ in range(2)]
+        self.work = [None, None]
+        self.rows = [0, 0]
+        self.pending = None
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=dev)
+            self.sampled = [torch.cuda.Event() for _ in range(2)]
+            self.gathered = [torch.cuda.Event() for _ in range(2)]
+            self.consumed = [None, None]
+
+    def local(self, k):
+        """this rank's slab buffer for chunk k; safe to overwrite once submit(k - 1) has returned"""
+        return self.send[k & 1]
+
+    def _start(self, k, rows):
+        t, b = self.t, k & 1
+        dist = _dist()
+        src = self.send[b]
+        recv = self.recv[b][:, :rows] if rows == self.recv[b].shape[1] else None
+        if self.cuda:
+            main = t.cuda.current_stream(src.device)
+            self.sampled[b].record(main)                 # chunk k's kernels are enqueued up to here
+            if self.consumed[b] is not None:             # whoever read recv[b] (two chunks ago) is done by then
+                self.side.wait_event(self.consumed[b])
+            self.side.wait_event(self.sampled[b])
+            ctx = t.cuda.stream(self.side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.pad:
+                self.sendpad[b][:rows, :, :src.shape[2]].copy_(src[:rows])
+                src = self.sendpad[b]
+            if recv is None:   # a short last chunk: gather the rows that exist into a dense sub-buffer
+                recv = self.recv[b].view(-1)[:self.world * rows * src.shape[1] * src.shape[2]].view(
+                    self.world, rows, src.shape[1], src.shape[2])
+            if self.world > 1:
+                self.work[b] = dist.all_gather_into_tensor(recv.view(self.world * rows, *recv.shape[2:]),
+                                                           src[:rows].contiguous(), group=self.group, async_op=True)
+            else:
+                recv[0].copy_(src[:rows])
+            if self.cuda:
+                if self.work[b] is not None:
+                    self.work[b].wait()                  # orders the SIDE stream after the collective
+                self.gathered[b].record(self.side)
+        self.rows[b] = rows
+        self._views = getattr(self, "_views", [None, None])
+        self._views[b] = recv
+
+    def _hand_out(self, k):
+        b = k & 1
+        if self.cuda:
+            main = self.t.cuda.current_stream(self.recv[b].device)
+            main.wait_event(self.gathered[b])            # the consumer's work is enqueued behind the gather
+            ev = self.t.cuda.Event()
+            self.consumed[b] = ev                        # recorded by the NEXT submit / finish, see _mark
+            self._to_mark = (b, ev)
+        elif self.work[b] is not None:
+            self.work[b].wait()
+        self.work[b] = None
+        return GatheredBlocks(self._views[b], self.sizes)
+
+    def _mark(self):
+        # everything the consumer enqueued on the sampling stream since the last hand-out is recorded now
+        tm = getattr(self, "_to_mark", None)
+        if tm is not None and self.cuda:
+            b, ev = tm
+            ev.record(self.t.cuda.current_stream(self.recv[b].device))
+        self._to_mark = None
+
+    def submit(self, k, rows=None):
+        self._mark()
+        rows = self.send[k & 1].shape[0] if rows is None else int(rows)
+        self._start(k, rows)
+        done = self._hand_out(self.pending) if self.pending is not None else None
+        self.pending = k
+        return done
+
+    def finish(self):
+        self._mark()
+        if self.pending is None:
+            return None
+        done = self._hand_out(self.pending)
+        self.pending = None
+        return done
 
 
 def ensemble_weights(H_local, beta=1.0, group=None):
@@ -166,5 +372,33 @@ def get_samples_sharded(potential, numDimensions, numParticles, simulTime, stepS
                           if rng == "numpy" else None, jitter=jitter, burn_in=burn_in)
     s_sdn, m_sdn = s.permute(2, 0, 1), m.permute(2, 0, 1)  # back to the (S, D, N_local) slabs
     if gather and world > 1:
-        s_sdn, m_sdn = gather_samples(s_sdn, group), gather_samples(m_sdn, group)
+        s_sdn = gather_samples(s_sdn, group, n_total=numParticles)
+        m_sdn = gather_samples(m_sdn, group, n_total=numParticles)
     return s_sdn.permute(1, 2, 0), m_sdn.permute(1, 2, 0), hmc
+
+
+def sample_chunks_sharded(potential, numDimensions, numParticles, simulTime, stepSize, numSamples, chunk,
+                          temperature, qStd, method="Leapfrog", rng="philox", seed=0, mass=None, compat=True,
+                          group=None, verbose=False, kdk_fma=None, draw_f64=False, momenta=False):
+    """A long sharded run collected WHILE it samples: the ensemble of `numParticles` chains is
+    sharded over the process group, sampled in chunks of `chunk` iterations, and chunk k's all-gather (RCCL
+    over xGMI) runs on a side stream while chunk k+1's kernels run -- two send and two receive buffers,
+    received in place, nothing re-laid.  Generator of (GatheredBlocks samples, GatheredBlocks momenta | None,
+    hmc) per chunk: `.blocks` is (world, c, D, N_max), `.view4()` the (c, D, world, N_max) view, `.to_sdn()`
+    a contiguous copy; a chunk's buffers are overwritten two chunks later.  The concatenated chunks equal
+    ONE get_samples_sharded / single-process run bit for bit (both RNG modes, any split)."""
+    from .ensemble import Ensemble
+    from .HMC import HMC
+    dist = _dist()
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    lo, hi = shard_bounds(numParticles, rank, world)
+    ens = Ensemble(numDimensions, hi - lo)
+    if mass is not None:
+        ens.mass = np.asarray(mass, dtype=np.float64)[lo:hi].copy()
+    hmc = HMC(ens, simulTime, stepSize, None, potential=potential, method=method, compat=compat, rng=rng,
+              seed=seed, verbose=verbose, kdk_fma=kdk_fma, draw_f64=draw_f64)
+    hs = HostStream(numDimensions, numParticles, lo, hi) if rng == "numpy" else None
+    yield from hmc.sampleChunksGathered(numSamples, chunk, temperature, qStd, n_total=numParticles, chain0=lo,
+                                        host_stream=hs, momenta=momenta, group=group)

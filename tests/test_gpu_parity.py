@@ -422,7 +422,7 @@ def test_error_behaviour(P, lib):
     with pytest.raises(ValueError, match="Invalid integration method selected."):
         P.HMC(ens, 1.0, 0.1, None, potential=pot, method="Euler")       # src/HMC.py:70-71
     with pytest.raises(TypeError):
-        P.HMC(ens, 1.0, 0.1, None, potential=lambda q: 0.5 * q @ q)      # no host fallback
+        P.HMC(ens, 1.0, 0.1, None, potential=lambda q: float(q[0]) ** 2)  # untraceable: no host fallback
     with pytest.raises(NotImplementedError):
         P.Integrator(ens, 0.1, 1.0, pot.gradient).integrate()           # src/integrator.py:87-91
     with pytest.raises(IndexError):
@@ -2410,3 +2410,30 @@ def test_class_api_draw_f64(P, lib):
                   verbose=False)
     s32, _ = hmc32.getSamples(S, 1.0 / kB, 0.7)
     assert not np.array_equal(s32, s)
+
+
+@pytest.mark.parametrize("rng", ["philox", "numpy"])
+def test_sample_chunks_gathered_equal_one_run(P, rng):
+    """distributed.sample_chunks_sharded / HMC.sampleChunksGathered (collection overlapped with sampling: side
+    stream, two send / two receive buffers) on ONE process: the concatenated chunks are getSamples' result bit
+    for bit, in both RNG modes, with a short last chunk, momenta included."""
+    from physicsbasedbayesianinference_amd.distributed import get_samples_sharded, sample_chunks_sharded
+    D, N, S, chunk, seed = 12, 333, 11, 4, 5
+    rs = np.random.RandomState(1)
+    pot = P.GaussianDiag(rs.standard_normal(D), prec=rs.uniform(0.5, 2.0, D), const=0.0)
+    m = 1.0 + (np.arange(N) % 3) * 0.5
+    np.random.seed(seed)
+    s_ref, m_ref, h_ref = get_samples_sharded(pot, D, N, 0.5, 0.1, S, 1.0 / kB, 1.0, rng=rng, seed=seed, mass=m)
+    np.random.seed(seed)
+    got_s, got_m, last = [], [], None
+    for bs, bm, hmc in sample_chunks_sharded(pot, D, N, 0.5, 0.1, S, chunk, 1.0 / kB, 1.0, rng=rng, seed=seed, mass=m,
+                                             momenta=True):
+        assert bs.blocks.shape[0] == 1 and bs.sizes == [N] and bs.view4().shape[2:] == (1, N)
+        got_s.append(bs.to_sdn().cpu().numpy())
+        got_m.append(bm.to_sdn().cpu().numpy())
+        last = hmc
+    got_s, got_m = np.concatenate(got_s), np.concatenate(got_m)
+    assert [len(x) for x in (got_s, got_m)] == [S, S]
+    assert np.array_equal(got_s, s_ref.permute(2, 0, 1).cpu().numpy())
+    assert np.array_equal(got_m, m_ref.permute(2, 0, 1).cpu().numpy())
+    assert abs(last.acceptRate - h_ref.acceptRate) < 1e-12
