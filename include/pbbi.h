@@ -243,6 +243,14 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
                  int64_t N, int64_t ldn, double h, int L, int S, int flags, uint64_t seed,
                  uint64_t iter0, uint64_t chain0, double kT, void* stream);
 
+/* What pbbi_hmc_run would do with these arguments, in words, written to out (NUL-terminated, truncated to
+ * out_len): the kernel family, whether the run carries the gradient between iterations and -- if not -- why
+ * (e.g. the dense D = 128 path stops carrying above N = 2^31 / (16 D) = 1 048 576 chains per call, where the
+ * two carried slabs pass the 32-bit buffer offsets), and how many iterations one launch covers.  Nothing is
+ * launched. */
+int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L, int S, int flags,
+                      char* out, int out_len);
+
 /* pbbi_hmc_iter_kt / pbbi_hmc_run with per-chain trajectory lengths (flags PBBI_PER_CHAIN_STEPS,
  * PBBI_UTURN_STOP above).  steps_in (N int32, device; iter only): the chains' step counts, each in
  * [0, L]; NULL = L for every chain.  steps_out (N, or (S, N) for run; may be NULL): the steps each

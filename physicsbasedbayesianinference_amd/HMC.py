@@ -49,7 +49,7 @@ class _HostDrawPipeline:
     class Slot:
         pass
 
-    def __init__(self, draw, S, D, N, device, np_dtype, depth=3):
+    def __init__(self, draw, S, D, N, device, np_dtype, depth=3, cache=None):
         import queue
         import threading
         from ._device import dev, torch, torch_dtype
@@ -62,6 +62,12 @@ class _HostDrawPipeline:
         self.thread = None
         self.stop = False
         self.finished = False
+        # the staging buffers outlive the call in `cache` (a dict owned by the HMC object: HMC.releaseHostBuffers
+        # empties it); the producer draws ahead of the launches, so the NumPy state BEFORE each iteration's draw
+        # is kept: a run that dies half way hands back the state that follows its last LAUNCHED iteration
+        self.cache = cache if cache is not None else {}
+        self.states = {}
+        self.launched = 0
         if self.S == 0:
             return
         self.side = t.cuda.Stream(device=dev(device))
@@ -71,8 +77,8 @@ class _HostDrawPipeline:
         # the staging buffers of the previous call with the same shape are kept (pinning 3 x D*N doubles takes
         # longer than a short run's draws); one shape at a time
         self.key = (int(D), int(N), str(td), str(dev(device)))
-        cached = _HostDrawPipeline._cache.pop(self.key, [])
-        _HostDrawPipeline._cache.clear()
+        cached = self.cache.pop(self.key, [])
+        self.cache.clear()
         self.slots = []
         for _ in range(min(depth, self.S)):
             if cached:
@@ -114,6 +120,8 @@ class _HostDrawPipeline:
                     return
                 if s.consumed is not None:
                     s.consumed.synchronize()
+                self.states[i] = np.random.get_state()   # (2.5 KB; iterations older than the slots are dropped)
+                self.states.pop(i - len(self.slots) - 1, None)
                 t0 = time.perf_counter()
                 if self.direct:   # float64 handle: the draws are written into the pinned buffers themselves
                     self.draw(i, s.pin_p.numpy(), s.pin_u.numpy())
@@ -142,6 +150,7 @@ class _HostDrawPipeline:
     def release(self, s):
         s.consumed = self.t.cuda.Event()
         s.consumed.record(self.main)
+        self.launched += 1
         self.free.put(s)
 
     def close(self):
@@ -152,9 +161,11 @@ class _HostDrawPipeline:
             # a run that went through keeps its staging buffers for the next call (getSamples synchronises the
             # device before it returns, so nothing reads them any more)
             if self.finished and self.error is None:
-                _HostDrawPipeline._cache[self.key] = list(self.slots)
-
-    _cache = {}
+                self.cache[self.key] = list(self.slots)
+            elif self.launched in self.states:
+                # the consumer gave up after `launched` iterations but the producer had drawn further: the global
+                # stream goes back to where the reference would have left it at that point
+                np.random.set_state(self.states[self.launched])
 
 class _Producer:
     """The process's host-draw thread: runs the pipelines' producer loops one after the other."""
@@ -246,6 +257,22 @@ class HMC:
         self.reject_masks = None   # (S, N) bool
         self.ratios = None         # (S, N) exp(oldH - newH)
         self.acceptRate = None
+        self._host_cache = {}      # rng="numpy": pinned staging buffers kept between getSamples calls
+
+    def describeRun(self, numSamples=2):
+        """What getSamples(numSamples, rng="philox") would launch, in words (pbbi_describe_run): the kernel
+        family, whether the gradient is carried between iterations (and why not), iterations per launch."""
+        import ctypes
+        buf = ctypes.create_string_buffer(1024)
+        N = self.ensemble.numParticles
+        _lib.call("pbbi_describe_run", self._pot.handle, self.integrator.method_id, N, N,
+                  int(self.integrator.numSteps), int(numSamples), self._flags(), buf, len(buf))
+        return buf.value.decode()
+
+    def releaseHostBuffers(self):
+        """Drop the pinned host / device staging buffers the rng="numpy" pipeline keeps between calls (three
+        (D, N) + (N,) pairs: ~200 MB pinned and ~200 MB of HBM at config C2); the next call pins new ones."""
+        self._host_cache.clear()
 
     # ------------------------------------------------------------------ helpers
     def potentialFunc(self, q):
@@ -370,7 +397,7 @@ class HMC:
         # The NumPy legacy stream can only be drawn in order, on the host (~15 ns per normal):
         # a producer thread draws iteration i+1 into pinned memory and starts its upload on a
         # side stream while iteration i's kernel runs (_HostDrawPipeline above).
-        run.pipe = _HostDrawPipeline(draw, S, D, N, dev, dt)
+        run.pipe = _HostDrawPipeline(draw, S, D, N, dev, dt, cache=self._host_cache)
         md = self._mass()
         mptr = md.data_ptr() if md is not None else None
         L, h, flags, stream = self.integrator.numSteps, float(self.stepSize), self._flags(), stream_ptr(dev)
@@ -445,6 +472,9 @@ class HMC:
                 run.pipe.finished = True  # every iteration was launched: the staging buffers may be kept
             finally:
                 run.pipe.close()
+                if not run.pipe.finished and run.pipe.direct and S > 0:
+                    # a run that died leaves no alias of a pinned staging buffer behind
+                    self.integrator.p = ens.p = np.array(ens.p, copy=True)
             pipe = run.pipe
             self.host_rng_ms = pipe.draw_seconds * 1e3 / max(S, 1)
         elif rng == "philox":

@@ -414,6 +414,21 @@ static int pass_cpus(cpu_set_t* target, int threads) { (void)target; (void)threa
 #define HS_PIN_END()
 #endif
 
+/* Test knob (tests/test_host_logic.py): how many attempts a pass asks for -- factor x expectation + extra, in
+ * chunks of 2^chunk_log2.  The defaults (2 % + 1024 attempts, chunks of 32 768) make a second pass a > 100 sigma
+ * event; a factor < 1 and small chunks force the shortfall passes (acc0 / att0 continuation, buffers regrown)
+ * that no ordinary call reaches.  Results do not depend on the knob. */
+static double g_pass_factor = 1.02;
+static int64_t g_pass_extra = 1024;
+static int g_pass_chunk_log2 = 15;
+static int g_last_passes = 0;
+void pbbi_host_debug_set_pass(double factor, int64_t extra, int chunk_log2) {
+    g_pass_factor = factor > 0.0 ? factor : 1.02;
+    g_pass_extra = extra >= 0 ? extra : 1024;
+    g_pass_chunk_log2 = (chunk_log2 >= 4 && chunk_log2 <= 20) ? chunk_log2 : 15;
+}
+int pbbi_host_debug_last_passes(void) { return g_last_passes; }
+
 static int normal_core(hs_state* st, double* out, int64_t n, const double* scale, int64_t ncol) {
     if (n <= 0) return 0;
     const int had_gauss = st->has_gauss;
@@ -429,7 +444,8 @@ static int normal_core(hs_state* st, double* out, int64_t n, const double* scale
         if (done == n) { stream_free(&s); return 0; }
     }
     const int64_t pairs = (n - done + 1) / 2;  /* accepted attempts needed (the last may leave a cached variate) */
-    const int64_t CH = 1 << 15;                /* attempts per chunk: 512 KB of words, L2-resident between the two passes */
+    const int64_t CH = (int64_t)1 << g_pass_chunk_log2;   /* attempts per chunk (32 768: 512 KB of words, L2-resident between the two passes) */
+    g_last_passes = 0;
     int64_t att_done = 0, acc_done = 0;        /* attempts examined, pairs written */
     int64_t* pref = NULL;
     double last_second = 0.0;
@@ -446,7 +462,9 @@ static int normal_core(hs_state* st, double* out, int64_t n, const double* scale
     (void)pin;
     while (acc_done < pairs) {
         /* expected attempts for what is missing, plus a margin; at least one chunk */
-        int64_t want = (int64_t)((double)(pairs - acc_done) / 0.7853981633974483 * 1.02) + 1024;
+        int64_t want = (int64_t)((double)(pairs - acc_done) / 0.7853981633974483 * g_pass_factor) + g_pass_extra;
+        if (want < 1) want = 1;
+        ++g_last_passes;
         const int64_t nch = (want + CH - 1) / CH;
         want = nch * CH;
         hs_pass ps;

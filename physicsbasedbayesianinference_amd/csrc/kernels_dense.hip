@@ -723,6 +723,14 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
 
     // ---- g(q_0) in row passes: U(q_old) and the first half kick
     const double ck = h * minv, ckh = 0.5 * ck;  // kick coefficients h/m and h/(2m)
+    int Ln = prm.L;  // this chain's steps
+    if constexpr (DYN) {  // drawn or uploaded, in [0, L] (include/pbbi.h); 0: the chain does not move at all
+        if (rng) Ln = (prm.flags & PBBI_PER_CHAIN_STEPS)
+                          ? rng_steps(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc), prm.L) : prm.L;
+        else if (prm.steps_in) Ln = prm.steps_in[n0 + cc];
+        Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
+    }
+    const double ck0 = (DYN && Ln == 0) ? 0.0 : ckh;  // a chain with no step gets no opening half kick either
     if constexpr (CARRY == 2) {
         if constexpr (!FUSE) carry_load(P0{});
     } else {
@@ -730,19 +738,18 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     }
     if constexpr (CARRY == 1) carry_store(P0{}, vg_cur);
     double xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
-    kick_pass<NT, NTP, 0>(vh, acc, ckh);
+    kick_pass<NT, NTP, 0>(vh, acc, ck0);
     if constexpr (NPASS == 2) {
         if constexpr (CARRY == 2) carry_load(P1{});
         else matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, vh, acc, h);
         if constexpr (CARRY == 1) carry_store(P1{}, vg_cur);
         xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
-        kick_pass<NT, NTP, 1>(vh, acc, ckh);
+        kick_pass<NT, NTP, 1>(vh, acc, ck0);
     }
     // H(q_old, p_old) now, so that only one double stays live across the trajectory
     const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
     STAMP(4);
-    xg = 0.0;
-    int Ln = prm.L;  // this chain's steps
+    if constexpr (!DYN) xg = 0.0;  // (DYN keeps x.g(q_0): a wave none of whose chains steps ends where it started)
     if constexpr (DYN) {
         // Per-chain lengths.  Chain c takes Ln <= L steps (drawn or uploaded) and, with PBBI_UTURN_STOP, stops
         // at the first step j where (q_j - q_0) . v_j < 0.  The 16-chain tile keeps stepping while any of its
@@ -755,10 +762,6 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         //     extra step that moves nothing.  v_j for the test is vh_{j-1/2} - (h/2m) g_j, formed pass by pass
         //     before the kick; q_0 is re-read from the iteration's input (the start point does not fit the
         //     registers).
-        if (rng) Ln = (prm.flags & PBBI_PER_CHAIN_STEPS)
-                          ? rng_steps(prm.seed, iter_k, prm.chain0 + (uint64_t)(n0 + cc), prm.L) : prm.L;
-        else if (prm.steps_in) Ln = prm.steps_in[n0 + cc];
-        Ln = Ln < 1 ? 1 : (Ln > prm.L ? prm.L : Ln);
         const bool uturn = (prm.flags & PBBI_UTURN_STOP) != 0;
         bool alive = true;
         double pend = 0.0;  // kick coefficient owed (0 or -h/2m)

@@ -728,6 +728,25 @@ int lane_hmc_iter(const IterArgs& a) {
     if (!no_lane2 && lane2_applies(a)) return lane2_hmc_iter(a);
     return launch_hmc<double>(a);
 }
+// which kernel family lane_hmc_iter hands these arguments to (pbbi_describe_run)
+const char* lane_route_name(const IterArgs& a) {
+    if (pbbi_dyn(a)) {
+        if (getenv("PBBI_NO_LANE2") == nullptr && lane2_applies(a) && !streams(a.pot))
+            return "k_ros2_hmc<DYN>: two lanes per chain, per-chain trajectory lengths";
+        return "k_lane_dyn_hmc: one chain per lane, per-chain trajectory lengths";
+    }
+    if (sepn_applies(a)) return "k_sep_hmc: separable potential, 16-dim parts in the waves of a workgroup, kick-drift-kick with FMA";
+    if (sepx_applies(a)) return "k_sep_exact_hmc: separable potential, 16-dim parts in the waves of a workgroup, reference operation order";
+    if (rosgx_applies(a)) return "k_rosg_exact_hmc: Rosenbrock, 4 / 8 lanes of a wave per chain, reference operation order";
+    if (rosg_applies(a)) return "k_rosg_hmc: Rosenbrock, 4 / 8 lanes of a wave per chain, kick-drift-kick with FMA";
+    if (rosn_applies(a)) return "k_rosn_hmc: Rosenbrock, 16-dim parts in the waves of a workgroup, kick-drift-kick with FMA";
+    if (streams(a.pot)) return "k_stream_hmc: one chain per lane, state in a device workspace (D > 64 or fp32)";
+    if (getenv("PBBI_NO_LANE2") == nullptr && lane2_applies(a))
+        return (a.flags & PBBI_KDK_FMA) ? "k_ros2_hmc: Rosenbrock 16 < D <= 32, two lanes per chain, kick-drift-kick with FMA"
+                                        : "k_ros2_hmc: Rosenbrock 16 < D <= 32, two lanes per chain, reference operation order";
+    return "k_lane_hmc: one chain per lane, state in registers, reference operation order";
+}
+
 int lane_dyn_hmc_iter(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->dtype != PBBI_F64 || pot->D > 32 || a.method != PBBI_LEAPFROG)

@@ -825,6 +825,54 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     return rc;
 }
 
+// what pbbi_hmc_run would do with these arguments, in words (include/pbbi.h)
+int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L, int S, int flags,
+                      char* out, int out_len) {
+    if (int rc = hmc_check(pot, method, N, ldn, L)) return rc;
+    if (!out || out_len < 1) return pbbi_fail(PBBI_ERR_INVALID, "out buffer missing");
+    IterArgs a{};
+    a.pot = pot; a.method = method; a.N = N; a.ldn_in = ldn; a.ldn_out = N; a.L = L; a.flags = flags; a.rng = 1;
+    a.kT = 1.0;
+    // (the fused-launch queries look at the carry buffers only for presence)
+    a.carry = 2; a.carry_g = (void*)(uintptr_t)16; a.carry_sel = (uint8_t*)(uintptr_t)16;
+    std::string d;
+    int fuse = 1;
+    if (pot->kind == KIND_CUSTOM) {
+        d = "user-potential plugin kernels (one chain per lane; registers up to D = 16 / 32, workspace beyond)";
+        fuse = route_fused_iterations(a);
+    } else if (is_big(pot)) {
+        d = "kernels_big: one fused MFMA GEMM per leapfrog step over the whole ensemble";
+        d += big_carry_applies(a) && S >= 2 ? "; gradient carried between iterations: yes (L GEMMs per iteration)"
+                                            : "; gradient carried between iterations: no (L + 1 GEMMs per iteration)";
+    } else if (is_dense(pot)) {
+        d = "k_dense_hmc: register-resident MFMA kernel, 16 chains per wave";
+        const bool carry = S >= 2 && dense_carry_applies(a);
+        if (carry) {
+            d += "; gradient carried between iterations: yes (L mat-vecs per iteration)";
+        } else {
+            d += "; gradient carried between iterations: no (L + 1 mat-vecs per iteration) -- ";
+            const uint64_t lim = ((uint64_t)1 << 31) / ((uint64_t)pot->D * 16u);
+            if (S < 2) d += "a run of one iteration";
+            else if (method != PBBI_LEAPFROG || L < 1 || pbbi_dyn(a)) d += "plain Leapfrog runs with L >= 1 only";
+            else if (pot->DP != 128) d += "the carried form exists for 64 < D <= 128";
+            else if ((uint64_t)N > lim)
+                d += "the two carried-gradient slabs (D*N*16 bytes) must stay below 2^31 for 32-bit buffer offsets: "
+                     "at D = " + std::to_string(pot->D) + " that is N <= " + std::to_string(lim) +
+                     " chains per call; shard the ensemble or split the call";
+            else d += "switched off (PBBI_NO_CARRY / PBBI_DENSE_V1)";
+        }
+        if (!carry) a.carry = 0;
+        fuse = carry ? dense_fused_iterations(a) : 1;
+    } else {
+        d = lane_route_name(a);
+        fuse = lane_fused_iterations(a);
+    }
+    d += "; iterations per launch: up to " + std::to_string(fuse < 1 ? 1 : fuse);
+    if (flags & PBBI_DRAW_F64) d += "; momentum draw: double precision";
+    snprintf(out, (size_t)out_len, "%s", d.c_str());
+    return PBBI_OK;
+}
+
 // ============================================================================ RNG
 int pbbi_philox_normal(uint64_t seed, int rng_stream, uint64_t iter, uint64_t chain0, int D,
                        int64_t N, int64_t ldn, double scale, const void* scale_per_chain,

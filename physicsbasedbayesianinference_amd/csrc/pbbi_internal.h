@@ -188,6 +188,7 @@ int lane2_hmc_iter(const IterArgs& a);
 // how many consecutive iterations of pbbi_hmc_run one call of route_hmc may cover for these arguments
 // (1 = the path has no fused form); lane_fused_iterations: kernels_lane.hip
 int lane_fused_iterations(const IterArgs& a);
+const char* lane_route_name(const IterArgs& a);  // the kernel family lane_hmc_iter picks (pbbi_describe_run)
 // per-chain trajectory lengths (k_lane_dyn_hmc: elementwise potentials, fp64, D <= 32, Leapfrog)
 int lane_dyn_hmc_iter(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip

@@ -1826,7 +1826,9 @@ def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
     if rng == "upload":
         p0 = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
         u = rs.uniform(size=N)
-        steps_in = rs.randint(1, L + 1, size=N).astype(np.int32)
+        steps_in = rs.randint(0, L + 1, size=N).astype(np.int32)   # [0, L] as include/pbbi.h says: 0 = no move
+        steps_in[-16:] = 0                                          # a whole 16-chain tile that takes no step
+        steps_in[:3] = (0, L, 0)
         pd, ud, sd = as_device(p0, 0, np.float64), as_device(u, 0, np.float64), torch.tensor(steps_in, device="cuda")
         lib.call("pbbi_hmc_iter_dyn", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
                  md.data_ptr() if mass else None, sd.data_ptr(), qo.data_ptr(), po.data_ptr(), ro.data_ptr(),
@@ -1844,9 +1846,13 @@ def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
     torch.cuda.synchronize()
     q_or, p_or = q0.copy(), p0.copy()
     r_or, rej_or, st_or = orc.hmc_iter_dyn(op, q_or, p_or, u, m, h, L, steps_in=steps_in)
-    assert np.array_equal(to_numpy(so), st_or) and len(np.unique(st_or)) == L
+    assert np.array_equal(to_numpy(so), st_or) and len(np.unique(st_or)) == L + (1 if rng == "upload" else 0)
     assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
     assert scaled_err(to_numpy(qo), q_or) <= RTOL_DENSE and scaled_err(to_numpy(po), p_or) <= RTOL_DENSE
+    if rng == "upload":   # chains with no step: the position they started from, bit for bit; never rejected
+        still = steps_in == 0
+        assert still.sum() >= 18 and np.array_equal(to_numpy(qo)[:, still], q0[:, still])
+        assert not to_numpy(rj).astype(bool)[still].any()
 
 
 @pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True)])
@@ -2437,3 +2443,73 @@ def test_sample_chunks_gathered_equal_one_run(P, rng):
     assert np.array_equal(got_s, s_ref.permute(2, 0, 1).cpu().numpy())
     assert np.array_equal(got_m, m_ref.permute(2, 0, 1).cpu().numpy())
     assert abs(last.acceptRate - h_ref.acceptRate) < 1e-12
+
+
+def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
+    """pbbi_describe_run: the kernel family, the carried-gradient state (with the N = 2^31 / (16 D) cliff of the
+    dense path spelled out) and the iterations per launch, without launching anything."""
+    import ctypes
+    Pm = np.eye(128) + 0.01
+
+    def describe(pot, N, L=10, S=100, flags=1, method=0):
+        buf = ctypes.create_string_buffer(1024)
+        lib.call("pbbi_describe_run", pot.handle, method, N, N, L, S, flags, buf, len(buf))
+        return buf.value.decode()
+    dense = P.GaussianDense(None, precision=Pm, const=0.0)
+    d = describe(dense, 65536)
+    assert "k_dense_hmc" in d and "carried between iterations: yes" in d and "up to 64" in d
+    d = describe(dense, 1 << 20)                      # one chain past the cliff
+    assert "carried between iterations: no" in d and "N <= 1048575" not in d and "N <= 1048576" in d and "shard" in d
+    assert "carried between iterations: yes" in describe(dense, (1 << 20) - 1)
+    assert "plain Leapfrog" in describe(dense, 1000, method=1)
+    assert "64 < D <= 128" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
+    assert "k_ros2_hmc" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.KDK_FMA)
+    assert "double precision" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.DRAW_F64)
+    assert "k_sep_hmc" in describe(P.GaussianDiag(np.zeros(64), prec=np.ones(64), const=0.0), 4096, flags=1 | lib.KDK_FMA)
+    assert "kernels_big" in describe(P.GaussianDense(None, precision=np.eye(256), const=0.0), 512)
+    hmc = P.HMC(P.Ensemble(128, 256), 1.0, 0.1, None, potential=dense, rng="philox", verbose=False)
+    assert "k_dense_hmc" in hmc.describeRun(10)
+
+
+def test_numpy_stream_run_that_dies_hands_back_the_right_rng_state(P, monkeypatch):
+    """The rng="numpy" producer thread draws ahead of the launches.  When a launch raises, the global NumPy
+    stream must be where the reference's would be after the iterations that WERE launched (its loop draws p and u
+    of iteration i right before using them, src/HMC.py:154,168), ens.p must not alias a pinned staging buffer, and
+    releaseHostBuffers() drops the cached staging buffers."""
+    from physicsbasedbayesianinference_amd import _lib
+    D, N, S, fail_at, seed = 4, 3000, 8, 3, 17
+    pot = P.StandardGaussian(D)
+    ens = P.Ensemble(D, N)
+    hmc = P.HMC(ens, 0.3, 0.1, None, potential=pot, verbose=False)
+    real_call, count = _lib.call, [0]
+
+    def flaky(name, *args):
+        if name == "pbbi_hmc_iter_kt":
+            count[0] += 1
+            if count[0] == fail_at + 1:
+                raise _lib.PbbiError(-3, "injected failure")
+        return real_call(name, *args)
+    monkeypatch.setattr(_lib, "call", flaky)
+    np.random.seed(seed)
+    with pytest.raises(_lib.PbbiError):
+        hmc.getSamples(S, 1.0 / kB, 1.0)
+    after = np.random.standard_normal(3)
+    # the reference at that point: q0, then fail_at complete iterations (p and u each), then the p of the
+    # iteration whose launch failed has NOT been consumed by our loop (it raised before using it)
+    rs = np.random.RandomState(seed)
+    rs.standard_normal((D, N))
+    for _ in range(fail_at):
+        rs.standard_normal((D, N))
+        rs.uniform(size=N)
+    assert np.array_equal(after, rs.standard_normal(3))
+    assert isinstance(ens.p, np.ndarray) and ens.p.flags.owndata
+    # a healthy run afterwards, then the staging buffers can be dropped and re-made
+    monkeypatch.setattr(_lib, "call", real_call)
+    np.random.seed(seed)
+    s1, _ = hmc.getSamples(3, 1.0 / kB, 1.0)
+    assert hmc._host_cache
+    hmc.releaseHostBuffers()
+    assert not hmc._host_cache
+    np.random.seed(seed)
+    s2, _ = hmc.getSamples(3, 1.0 / kB, 1.0)
+    assert np.array_equal(s1, s2)

@@ -395,6 +395,47 @@ def test_fast_host_stream_is_numpys_legacy_stream_bit_for_bit(monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(ref, got))
 
 
+def test_fast_host_stream_shortfall_passes(monkeypatch):
+    """normal_core's second and later passes (the first pass accepted fewer pairs than needed: acc0 / att0
+    continuation, prefix array and word buffer regrown) are a > 100 sigma event with the shipped margin, so
+    a test knob (pbbi_host_debug_set_pass) shrinks the request per pass and the chunk: values AND the
+    MT19937 state handed back must still be NumPy's, whatever the number of passes and threads."""
+    import ctypes as C
+    from physicsbasedbayesianinference_amd import _hoststream as hs
+    monkeypatch.setattr(hs, "MIN_FAST", 1)
+    lib = hs._load()
+    lib.pbbi_host_debug_set_pass.argtypes = [C.c_double, C.c_int64, C.c_int]
+    lib.pbbi_host_debug_last_passes.restype = C.c_int
+    threads0 = lib.pbbi_host_threads()
+    try:
+        seen = set()
+        for factor, extra, log2ch in ((0.5, 0, 8), (0.3, 7, 6), (0.9, 0, 10), (0.05, 1, 4)):
+            for threads in (1, 2, 5):
+                lib.pbbi_host_set_threads(threads)
+                lib.pbbi_host_debug_set_pass(factor, extra, log2ch)
+                for seed, sizes, cached in ((5, [1000, 4097, 3], False), (6, [20001], True), (7, [(3, 777), 2], True)):
+                    np.random.seed(seed)
+                    if cached:
+                        np.random.standard_normal(1)
+                    ref = [np.random.standard_normal(n) for n in sizes] + [np.random.uniform(size=5)]
+                    st_ref = np.random.get_state()
+                    np.random.seed(seed)
+                    if cached:
+                        np.random.standard_normal(1)
+                    got = []
+                    for n in sizes:
+                        got.append(hs.standard_normal(n))
+                        seen.add(lib.pbbi_host_debug_last_passes())
+                    got.append(hs.uniform(5))
+                    assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (factor, threads, seed)
+                    st = np.random.get_state()
+                    assert st[0] == st_ref[0] and np.array_equal(st[1], st_ref[1]) and st[2:] == st_ref[2:]
+        assert max(seen) >= 3 and len(seen) >= 3, seen     # the multi-pass code really ran
+    finally:
+        lib.pbbi_host_debug_set_pass(1.02, 1024, 15)
+        lib.pbbi_host_set_threads(threads0)
+
+
 def test_fast_host_stream_in_place_draws(monkeypatch):
     """scaled_normal_into / uniform_into (the class API's per-iteration draws, written straight into the
     upload buffers) equal `standard_normal((D, N)) * pStd` and `uniform(size=N)` bit for bit, state included;

@@ -294,3 +294,15 @@ def test_f64_draw_tail_reach():
     assert abs(zc - np.sqrt(106 * np.log(2.0))) < 1e-14 and zs == 0.0
     zc, zs = G.box_muller([0xFFF, 0, 0, 0x40000000])      # still u1 = 2^-53; angle pi/2
     assert abs(zs - np.sqrt(106 * np.log(2.0))) < 1e-14 and abs(zc) < 1e-15
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make -C oracle asan_check`: every oracle entry point driven over exactly-sized heap buffers with
+    -fsanitize=address,undefined (GPU sanitizers are unavailable on the pool; the CPU build is where they run)."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    res = subprocess.run(["make", "-C", here, "-B", "asan_check"], capture_output=True, text=True,
+                         env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1"})
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "asan ok" in res.stdout
