@@ -245,7 +245,7 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
 
 /* What pbbi_hmc_run would do with these arguments, in words, written to out (NUL-terminated, truncated to
  * out_len): the kernel family, whether the run carries the gradient between iterations and -- if not -- why
- * (e.g. the dense D = 128 path stops carrying above N = 2^31 / (16 D) = 1 048 576 chains per call, where the
+ * (e.g. the dense D = 128 path carries below N = 2^31 / (16 D) = 1 048 576 chains per call only: beyond, the
  * two carried slabs pass the 32-bit buffer offsets), and how many iterations one launch covers.  Nothing is
  * launched. */
 int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L, int S, int flags,
@@ -268,6 +268,27 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
                      void* samples_out, void* momenta_out, uint8_t* reject_out, void* ratio_out,
                      int32_t* steps_out, int64_t N, int64_t ldn, double h, int L, int S, int flags,
                      uint64_t seed, uint64_t iter0, uint64_t chain0, double kT, void* stream);
+
+/* ---- a reversible per-chain dynamic trajectory length: the self-tuning no-U-turn sampler ------------
+ * ("no u-turn sampling" is planned in the reference, references/PhysicsBasedHMC_SoHPC2022_WeekPlan.md:16-17;
+ * PBBI_UTURN_STOP alone only measures, see above.)  GIST (Bou-Rabee, Carpenter & Marsden 2024): with
+ * tau(q, p) = the number of leapfrog steps until (q_j - q_0) . p_j < 0 first holds, at most Lmax,
+ *     tau_f = tau(q, p);    L uniform on 1..tau_f  (1 + floor(u tau_f), u from PBBI_STREAM_STEPS);
+ *     (q', p') = L steps from (q, p);    tau_b = tau(q', -p');
+ *     accept with probability min(1, exp((H - H')/kT_or_1) * tau_f / tau_b * [L <= tau_b]).
+ * Every chain adapts its length to where it is, and the chain still leaves exp(-H) invariant: the length is a
+ * Gibbs draw whose density enters the Metropolis ratio at both ends.  One iteration is three masked
+ * trajectories (forward search, proposal, backward search: the per-chain-length kernels of
+ * pbbi_hmc_iter_dyn, so the same potentials / sizes are served: elementwise D <= 32, dense D <= 128, other
+ * handles return PBBI_ERR_UNSUPPORTED) plus an accept kernel; momenta are drawn by pbbi_philox_normal's
+ * kernel for the same counters as pbbi_hmc_run (PBBI_DRAW_F64 honoured), the Metropolis uniform is the
+ * chain's PBBI_STREAM_UNIFORM draw.  Arguments as pbbi_hmc_run (samples_out required); tau_out (S, 3, N)
+ * int32 or NULL receives tau_f, L, tau_b; ratio_out the full acceptance ratio.  flags: PBBI_COMPAT_P_FROM_OLDQ,
+ * PBBI_BETA_ACCEPT, PBBI_DRAW_F64.  Restated in oracle/pbbi_oracle.c::oracle_hmc_iter_gist. */
+int pbbi_hmc_run_gist(const pbbi_potential* pot, void* q_state, const void* mass, void* samples_out,
+                      void* momenta_out, uint8_t* reject_out, void* ratio_out, int32_t* tau_out, int64_t N,
+                      int64_t ldn, double h, int Lmax, int S, int flags, uint64_t seed, uint64_t iter0,
+                      uint64_t chain0, double kT, void* stream);
 
 /* ---- RNG (device Philox stream) -------------------------------------------
  * out[d*ldn+n] = scale * z(dim d, chain chain0+n); scale_per_chain (N) overrides

@@ -230,6 +230,29 @@ def hmc_iter_dyn(pot, q, p, u, mass, h, L, steps_in=None, uturn=False, compat=CO
     return ratio, rej.astype(bool), steps
 
 
+def hmc_iter_gist(pot, q, p, u_acc, u_len, mass, h, Lmax, compat=COMPAT_P_FROM_OLDQ, beta=1.0):
+    """One GIST (self-tuning no-U-turn) iteration in place on q, p (oracle_hmc_iter_gist).  Returns
+    (ratio, reject_mask, tau) with tau (3, N) = forward U-turn count, drawn length, backward U-turn count."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert Dq == D and p.shape == q.shape
+    m = _mass(mass, N)
+    u_acc = np.ascontiguousarray(u_acc, dtype=np.float64)
+    u_len = np.ascontiguousarray(u_len, dtype=np.float64)
+    ratio, rej, tau = np.empty(N), np.empty(N, dtype=np.uint8), np.empty((3, N), dtype=np.int32)
+    rc = lib().oracle_hmc_iter_gist(C.byref(st), _ptr(q), _ptr(p), _ptr(u_acc), _ptr(u_len), _ptr(m),
+                                    C.c_int64(N), C.c_int64(N), C.c_double(h), C.c_int(Lmax), C.c_int(compat),
+                                    C.c_double(beta), _ptr(ratio), _ptr(rej), tau.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return ratio, rej.astype(bool), tau
+
+
+def philox_steps_uniform(seed, it, chain0, N):
+    out = np.empty(N)
+    lib().oracle_philox_steps_uniform(C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0), C.c_int64(N), _ptr(out))
+    return out
+
+
 def philox_steps(seed, it, chain0, N, L):
     out = np.empty(N, dtype=np.int32)
     lib().oracle_philox_steps(C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0), C.c_int64(N), C.c_int(L),

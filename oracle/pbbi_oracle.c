@@ -445,6 +445,64 @@ int oracle_hmc_iter_dyn(const oracle_pot* P, int method, double* q, double* p, c
     return 0;
 }
 
+/* One iteration of the self-tuning ("GIST", Bou-Rabee, Carpenter & Marsden 2024) no-U-turn sampler: the
+ * reversible per-chain dynamic trajectory length the reference plans ("no u-turn sampling",
+ * references/PhysicsBasedHMC_SoHPC2022_WeekPlan.md:16-17) -- the build's own definition, include/pbbi.h
+ * pbbi_hmc_run_gist.  With tau(q, p) = number of leapfrog steps until (q_j - q_0) . p_j < 0 first holds,
+ * at most Lmax (leapfrog_chain_dyn with uturn):
+ *   tau_f = tau(q, p);   L = 1 + floor(u_len * tau_f) (capped at tau_f): uniform on 1..tau_f;
+ *   (q', p') = L leapfrog steps from (q, p);   tau_b = tau(q', -p');
+ *   accept with probability min(1, exp(beta (H - H')) * tau_f / tau_b * [L <= tau_b]).
+ * The length is a Gibbs draw from a state-dependent distribution and the Metropolis ratio carries that
+ * distribution's density at both ends, so the chain keeps exp(-beta H) invariant although L adapts to the
+ * local geometry.  tau_out: (3, N) = tau_f, L, tau_b.  Rejected chains as in oracle_hmc_iter (compat). */
+int oracle_hmc_iter_gist(const oracle_pot* P, double* q, double* p, const double* u_acc, const double* u_len,
+                         const double* mass, int64_t N, int64_t ldn, double h, int Lmax, int compat, double beta,
+                         double* ratio_out, unsigned char* reject_out, int32_t* tau_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD || Lmax < 1) return -1;
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 11 * D);
+        double *qc = buf, *pc = buf + D, *vc = buf + 2 * D, *a = buf + 3 * D, *b = buf + 4 * D, *tmp = buf + 5 * D,
+               *oq = buf + 6 * D, *op = buf + 7 * D, *q0 = buf + 8 * D, *qb = buf + 9 * D, *pb = buf + 10 * D;
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const double m = mass ? mass[n] : 1.0;
+            col_get(q, D, ldn, n, oq);
+            col_get(p, D, ldn, n, op);
+            memcpy(qc, oq, sizeof(double) * D);
+            memcpy(pc, op, sizeof(double) * D);
+            const int tau_f = leapfrog_chain_dyn(P, qc, pc, vc, m, h, Lmax, 1, a, b, tmp, q0);
+            int L = 1 + (int)(u_len[n] * (double)tau_f);
+            if (L > tau_f) L = tau_f;
+            memcpy(qc, oq, sizeof(double) * D);
+            memcpy(pc, op, sizeof(double) * D);
+            leapfrog_chain_dyn(P, qc, pc, vc, m, h, L, 0, a, b, tmp, q0);
+            for (int d = 0; d < D; ++d) { qb[d] = qc[d]; pb[d] = -pc[d]; }
+            const double oldH = hamiltonian(P, oq, op, m);
+            const double newH = hamiltonian(P, qc, pb, m);
+            const int tau_b = leapfrog_chain_dyn(P, qb, pb, vc, m, h, Lmax, 1, a, b, tmp, q0);
+            const double hratio = exp((oldH - newH) * beta);
+            const double ratio = (L <= tau_b) ? hratio * ((double)tau_f / (double)tau_b) : 0.0;
+            const double acc = (1.0 < ratio || ratio != ratio) ? ((ratio != ratio) ? ratio : 1.0) : ratio;
+            const int reject = (u_acc[n] > acc);
+            if (reject) {
+                col_put(q, D, ldn, n, oq);
+                col_put(p, D, ldn, n, (compat & COMPAT_P_FROM_OLDQ) ? oq : op);
+            } else {
+                col_put(q, D, ldn, n, qc);
+                col_put(p, D, ldn, n, pc);
+            }
+            if (ratio_out) ratio_out[n] = ratio;
+            if (reject_out) reject_out[n] = (unsigned char)reject;
+            if (tau_out) { tau_out[n] = tau_f; tau_out[N + n] = L; tau_out[2 * N + n] = tau_b; }
+        }
+        free(buf);
+    }
+    return 0;
+}
+
 /* ----------------------------------------------------------------- Philox RNG
  * Counter-based generator of the device ("philox") mode; the product's HIP
  * kernels implement the same contract (include/pbbi.h, "RNG contract").
@@ -612,6 +670,16 @@ int oracle_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N
         rng_block(seed, 3u, iter, chain0 + n, 0xFFFFFFFFu, x);
         int s = 1 + (int)(u53(x[0], x[1]) * (double)L);
         out[n] = L > 0 ? (s > L ? L : s) : 0;
+    }
+    return 0;
+}
+
+/* the uniform of PBBI_STREAM_STEPS (what PBBI_PER_CHAIN_STEPS and the GIST length draw consume) */
+int oracle_philox_steps_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, double* out) {
+    for (int64_t n = 0; n < N; ++n) {
+        uint32_t x[4];
+        rng_block(seed, 3u, iter, chain0 + n, 0xFFFFFFFFu, x);
+        out[n] = u53(x[0], x[1]);
     }
     return 0;
 }

@@ -534,6 +534,47 @@ class HMC:
             return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
         return self._to_dns(samples), self._to_dns(momenta)
 
+    def getSamplesGIST(self, numSamples, temperature, qStd, max_steps=None, seed=None, device_output=False, chain0=0,
+                       iter0=0):
+        """getSamples with a REVERSIBLE per-chain dynamic trajectory length: the self-tuning no-U-turn sampler
+        (GIST; pbbi_hmc_run_gist, include/pbbi.h) -- the "no u-turn sampling" the reference plans
+        (references/PhysicsBasedHMC_SoHPC2022_WeekPlan.md:16-17).  Every iteration every chain integrates forward
+        until its own U-turn ((q_j - q_0) . p_j < 0, at most max_steps: default 8 x numSteps), draws its
+        trajectory length uniformly below that, and accepts with min(1, e^{-dH} tau_f / tau_b [L <= tau_b]), where
+        tau_b is the U-turn count seen from the proposal backwards: lengths adapt to the local geometry chain by
+        chain and the target stays invariant.  In-kernel draws (rng="philox" counters; draw_f64 honoured);
+        Leapfrog; potentials the per-chain-length kernels serve (elementwise D <= 32, dense D <= 128).  Returns
+        (samples, momenta) like getSamples; self.gist_tau holds the (S, 3, N) counts tau_f, L, tau_b,
+        self.ratios the full acceptance ratios."""
+        pot, ens = self._pot, self.ensemble
+        D, N, S = ens.numDimensions, ens.numParticles, int(numSamples)
+        if self.integrator.method_id != _lib.LEAPFROG:
+            raise ValueError("GIST sampling integrates with Leapfrog")
+        seed = self.seed if seed is None else int(seed)
+        dev, dt = pot.device, pot.dtype
+        stream = stream_ptr(dev)
+        kT = float(boltzmannConst * temperature)
+        Lmax = int(max_steps) if max_steps else max(8, 8 * int(self.integrator.numSteps))
+        samples, momenta = empty((S, D, N), dt, dev), empty((S, D, N), dt, dev)
+        reject, ratio = empty((S, N), np.uint8, dev), empty((S, N), dt, dev)
+        tau = empty((S, 3, N), np.int32, dev)
+        md = self._mass()
+        q_state = empty((D, N), dt, dev)
+        _lib.call("pbbi_philox_normal", seed, self._position_stream(), int(iter0), int(chain0), D, N, N, float(qStd),
+                  None, pot._dt, dev, q_state.data_ptr(), stream)
+        flags = self._flags() & (_lib.COMPAT_P_FROM_OLDQ | _lib.BETA_ACCEPT | _lib.DRAW_F64)
+        _lib.call("pbbi_hmc_run_gist", pot.handle, q_state.data_ptr(), md.data_ptr() if md is not None else None,
+                  samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), ratio.data_ptr(), tau.data_ptr(), N, N,
+                  float(self.stepSize), Lmax, S, flags, seed, int(iter0), int(chain0), kT, stream)
+        synchronize(dev)
+        self.reject_masks = to_numpy(reject).astype(bool)
+        self.ratios = to_numpy(ratio)
+        self.gist_tau = to_numpy(tau)
+        self.acceptRate = 1.0 - float(self.reject_masks.mean()) if S > 0 and N > 0 else None
+        if device_output:
+            return samples.permute(1, 2, 0), momenta.permute(1, 2, 0)
+        return self._to_dns(samples), self._to_dns(momenta)
+
     def sampleChunks(self, numSamples, chunk, temperature, qStd, seed=None, chain0=0, iter0=0,
                      spill_dir=None, momenta=False):
         """Generator over a long in-kernel-draw run in chunks of `chunk` iterations (SURVEY 8f row 4:

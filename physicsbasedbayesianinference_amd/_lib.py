@@ -66,6 +66,7 @@ PROTOTYPES = {
                          _u64, _d, _vp],
     "pbbi_philox_steps": [_u64, _u64, _u64, _i64, _i, _i, _vp, _vp],
     "pbbi_describe_run": [_vp, _i, _i64, _i64, _i, _i, _i, C.c_char_p, _i],
+    "pbbi_hmc_run_gist": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64, _u64, _d, _vp],
     "pbbi_hmc_run": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64,
                      _u64, _d, _vp],
     "pbbi_philox_normal": [_u64, _i, _u64, _u64, _i, _i64, _i64, _d, _vp, _i, _i, _vp, _vp],

@@ -198,6 +198,61 @@ __global__ void k_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, in
     if (n < N) out[n] = L > 0 ? rng_steps(seed, iter, chain0 + n, L) : 0;
 }
 
+// ---- GIST (self-tuning no-U-turn) iteration pieces, pbbi_hmc_run_gist -------------------------------
+// L = 1 + floor(u * tau_f), capped at tau_f: uniform on 1..tau_f, u = the chain's PBBI_STREAM_STEPS uniform
+__global__ void k_gist_length(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, const int32_t* tau_f,
+                              int32_t* L_out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const PhiloxOut x = rng_block(seed, /*PBBI_STREAM_STEPS*/ 3u, iter, chain0 + (uint64_t)n, 0xFFFFFFFFu);
+    const int t = tau_f[n];
+    const int L = 1 + (int)(u53(x.x0, x.x1) * (double)t);
+    L_out[n] = L > t ? t : L;
+}
+
+template <typename T>
+__global__ void k_negate(const T* in, T* out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = -in[i];
+}
+
+template <typename T>
+__global__ void k_fill_zero(T* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = T(0);
+}
+
+template <typename T>
+__global__ void k_pstd(const T* mass, double kT, int64_t N, T* out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = (T)sqrt((double)mass[n] * kT);   // src/ensemble.py:88
+}
+
+// accept with min(1, exp(beta (H - H')) tau_f / tau_b [L <= tau_b]); rejected chains keep their position and
+// report the old position (compat, src/HMC.py:176) or the drawn momentum as momentum
+template <typename T>
+__global__ void k_gist_accept(const T* q_prev, int64_t ld_prev, const T* p_draw, const T* qB, const T* pB,
+                              const T* ratioB, const int32_t* tau_f, const int32_t* Ls, const int32_t* tau_b,
+                              uint64_t seed, uint64_t iter, uint64_t chain0, int D, int64_t N, int flags, T* q_out,
+                              T* p_out, T* ratio_out, uint8_t* reject_out, int32_t* tau_out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double hr = (double)ratioB[n];
+    const int tf = tau_f[n], L = Ls[n], tb = tau_b[n];
+    const double ratio = (L <= tb) ? hr * ((double)tf / (double)tb) : 0.0;
+    const double u = rng_uniform(seed, iter, chain0 + (uint64_t)n);
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    const bool compat = (flags & PBBI_COMPAT_P_FROM_OLDQ) != 0;
+    for (int d = 0; d < D; ++d) {
+        const T qo = q_prev[(int64_t)d * ld_prev + n];
+        q_out[(int64_t)d * N + n] = reject ? qo : qB[(int64_t)d * N + n];
+        if (p_out) p_out[(int64_t)d * N + n] = reject ? (compat ? qo : p_draw[(int64_t)d * N + n]) : pB[(int64_t)d * N + n];
+    }
+    if (ratio_out) ratio_out[n] = (T)ratio;
+    if (reject_out) reject_out[n] = reject ? 1 : 0;
+    if (tau_out) { tau_out[n] = tf; tau_out[N + n] = L; tau_out[2 * N + n] = tb; }
+}
+
 // (S, D*N) -> (D*N, S) tiled transpose through LDS: both sides coalesced.
 template <typename T>
 __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int S, int64_t M) {
@@ -451,6 +506,79 @@ int weights_reduce(const void* x, int64_t N, double beta, const double* hmin, in
 }  // namespace
 
 // ======================================================================= library
+// ---- one GIST run (pbbi_hmc_run_gist below): per iteration three masked trajectories and an accept kernel
+template <typename T>
+static int gist_run(const pbbi_potential* pot, void* q_state, const void* mass, void* samples_out, void* momenta_out,
+                    uint8_t* reject_out, void* ratio_out, int32_t* tau_out, int64_t N, int64_t ldn, double h,
+                    int Lmax, int S, int flags, uint64_t seed, uint64_t iter0, uint64_t chain0, double kT,
+                    hipStream_t st) {
+    const int D = pot->D;
+    const size_t slab = (size_t)D * (size_t)N;
+    Scratch ws(st);
+    T* p_draw = (T*)ws.get(slab * sizeof(T));
+    T* scrQ = (T*)ws.get(slab * sizeof(T));
+    T* scrP = (T*)ws.get(slab * sizeof(T));
+    T* qB = (T*)ws.get(slab * sizeof(T));
+    T* pB = (T*)ws.get(slab * sizeof(T));
+    T* negp = (T*)ws.get(slab * sizeof(T));
+    T* zeros = (T*)ws.get((size_t)N * sizeof(T));
+    T* ratioB = (T*)ws.get((size_t)N * sizeof(T));
+    T* pstd = mass ? (T*)ws.get((size_t)N * sizeof(T)) : nullptr;
+    int32_t* tf = (int32_t*)ws.get((size_t)N * 3 * sizeof(int32_t));
+    if (!p_draw || !scrQ || !scrP || !qB || !pB || !negp || !zeros || !ratioB || (mass && !pstd) || !tf)
+        return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the GIST workspace");
+    T* q0 = (T*)ws.get(slab * sizeof(T));
+    if (!q0) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the GIST workspace");
+    PBBI_HIP(hipMemcpy2DAsync(q0, (size_t)N * sizeof(T), q_state, (size_t)ldn * sizeof(T), (size_t)N * sizeof(T),
+                              (size_t)D, hipMemcpyDeviceToDevice, st));
+    int32_t *Ls = tf + N, *tb = tf + 2 * N;
+    const dim3 b(256), gN((unsigned)((N + 255) / 256)), gDN((unsigned)((slab + 255) / 256));
+    hipLaunchKernelGGL(k_fill_zero<T>, gN, b, 0, st, zeros, N);
+    if (mass) hipLaunchKernelGGL(k_pstd<T>, gN, b, 0, st, (const T*)mass, kT, N, pstd);
+    const bool f64 = (flags & PBBI_DRAW_F64) != 0;
+    const int base = flags & (PBBI_BETA_ACCEPT);   // the integrations run in the reference's operation order
+    int rc = PBBI_OK;
+    for (int i = 0; i < S && rc == PBBI_OK; ++i) {
+        const uint64_t it = iter0 + (uint64_t)i;
+        // iteration i starts from the state iteration i-1 recorded (dense slabs; q0: the caller's state, repacked)
+        const T* q_prev = (i == 0) ? (const T*)q0 : (const T*)samples_out + (size_t)(i - 1) * slab;
+        hipLaunchKernelGGL(k_philox_normal<T>, gN, b, 0, st, seed, PBBI_STREAM_MOMENTUM | (f64 ? PBBI_STREAM_DRAW_F64 : 0),
+                           it, chain0, D, N, N, sqrt(kT), (const T*)pstd, p_draw);
+        IterArgs a{};
+        a.pot = pot; a.method = PBBI_LEAPFROG; a.mass = mass; a.N = N; a.h = h; a.L = Lmax; a.rng = 0; a.kT = kT;
+        a.stream = st; a.u_in = zeros; a.ldn_in = N; a.ldn_out = N;
+        // (1) forward U-turn count tau_f = tau(q, p); the end state is not used
+        a.q_in = q_prev; a.p_in = p_draw; a.q_out = scrQ; a.p_out = scrP;
+        a.flags = base | PBBI_UTURN_STOP; a.steps_in = nullptr; a.steps_out = tf;
+        if ((rc = route_hmc(a)) != PBBI_OK) break;
+        // (2) L uniform on 1..tau_f
+        hipLaunchKernelGGL(k_gist_length, gN, b, 0, st, seed, it, chain0, N, (const int32_t*)tf, Ls);
+        // (3) the proposal: L_n steps from (q, p); ratioB = exp(beta (H - H')); u = 0 accepts every chain
+        a.q_out = qB; a.p_out = pB; a.ratio_out = ratioB; a.flags = base | PBBI_PER_CHAIN_STEPS;
+        a.steps_in = Ls; a.steps_out = nullptr;
+        if ((rc = route_hmc(a)) != PBBI_OK) break;
+        // (4) backward U-turn count tau_b = tau(q', -p')
+        hipLaunchKernelGGL(k_negate<T>, gDN, b, 0, st, (const T*)pB, negp, (int64_t)slab);
+        a.q_in = qB; a.p_in = negp; a.q_out = scrQ; a.p_out = scrP; a.ratio_out = nullptr;
+        a.flags = base | PBBI_UTURN_STOP; a.steps_in = nullptr; a.steps_out = tb;
+        if ((rc = route_hmc(a)) != PBBI_OK) break;
+        // (5) the accept test and the record
+        hipLaunchKernelGGL(k_gist_accept<T>, gN, b, 0, st, q_prev, N, (const T*)p_draw, (const T*)qB,
+                           (const T*)pB, (const T*)ratioB, (const int32_t*)tf, (const int32_t*)Ls, (const int32_t*)tb,
+                           seed, it, chain0, D, N, flags, (T*)samples_out + (size_t)i * slab,
+                           momenta_out ? (T*)momenta_out + (size_t)i * slab : nullptr,
+                           ratio_out ? (T*)ratio_out + (size_t)i * N : nullptr,
+                           reject_out ? reject_out + (size_t)i * N : nullptr,
+                           tau_out ? tau_out + (size_t)i * 3 * N : nullptr);
+    }
+    if (rc != PBBI_OK) return rc;
+    PBBI_HIP(hipGetLastError());
+    PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * sizeof(T), (const T*)samples_out + (size_t)(S - 1) * slab,
+                              (size_t)N * sizeof(T), (size_t)N * sizeof(T), (size_t)D, hipMemcpyDeviceToDevice, st));
+    return PBBI_OK;
+}
+
+
 extern "C" {
 
 int pbbi_version(void) { return PBBI_VERSION; }
@@ -825,6 +953,28 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     return rc;
 }
 
+int pbbi_hmc_run_gist(const pbbi_potential* pot, void* q_state, const void* mass, void* samples_out,
+                      void* momenta_out, uint8_t* reject_out, void* ratio_out, int32_t* tau_out, int64_t N,
+                      int64_t ldn, double h, int Lmax, int S, int flags, uint64_t seed, uint64_t iter0,
+                      uint64_t chain0, double kT, void* stream) {
+    if (int rc = hmc_check(pot, PBBI_LEAPFROG, N, ldn, Lmax)) return rc;
+    if (Lmax < 1) return pbbi_fail(PBBI_ERR_INVALID, "GIST: the U-turn search needs Lmax >= 1");
+    if (S < 0) return pbbi_fail(PBBI_ERR_INVALID, "S must be >= 0");
+    if (!(kT > 0.0)) return pbbi_fail(PBBI_ERR_INVALID, "kT must be > 0");
+    if (flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP | PBBI_KDK_FMA))
+        return pbbi_fail(PBBI_ERR_INVALID, "GIST: flags may hold PBBI_COMPAT_P_FROM_OLDQ, PBBI_BETA_ACCEPT, PBBI_DRAW_F64");
+    if (iter0 > UINT32_MAX || iter0 + (uint64_t)S > (uint64_t)UINT32_MAX + 1)
+        return pbbi_fail(PBBI_ERR_INVALID, "iter0 + S must be <= 2^32 (the Philox counter holds 32 iteration bits)");
+    if (S == 0 || N == 0) return PBBI_OK;
+    if (!q_state || !samples_out) return pbbi_fail(PBBI_ERR_INVALID, "q_state and samples_out must be non-NULL");
+    DeviceGuard guard(pot->device);
+    if (pot->dtype == PBBI_F64)
+        return gist_run<double>(pot, q_state, mass, samples_out, momenta_out, reject_out, ratio_out, tau_out, N, ldn, h,
+                                Lmax, S, flags, seed, iter0, chain0, kT, (hipStream_t)stream);
+    return gist_run<float>(pot, q_state, mass, samples_out, momenta_out, reject_out, ratio_out, tau_out, N, ldn, h, Lmax,
+                           S, flags, seed, iter0, chain0, kT, (hipStream_t)stream);
+}
+
 // what pbbi_hmc_run would do with these arguments, in words (include/pbbi.h)
 int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L, int S, int flags,
                       char* out, int out_len) {
@@ -851,7 +1001,7 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
             d += "; gradient carried between iterations: yes (L mat-vecs per iteration)";
         } else {
             d += "; gradient carried between iterations: no (L + 1 mat-vecs per iteration) -- ";
-            const uint64_t lim = ((uint64_t)1 << 31) / ((uint64_t)pot->D * 16u);
+            const uint64_t lim = (((uint64_t)1 << 31) - 1) / ((uint64_t)pot->D * 16u);
             if (S < 2) d += "a run of one iteration";
             else if (method != PBBI_LEAPFROG || L < 1 || pbbi_dyn(a)) d += "plain Leapfrog runs with L >= 1 only";
             else if (pot->DP != 128) d += "the carried form exists for 64 < D <= 128";

@@ -2459,7 +2459,7 @@ def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
     d = describe(dense, 65536)
     assert "k_dense_hmc" in d and "carried between iterations: yes" in d and "up to 64" in d
     d = describe(dense, 1 << 20)                      # one chain past the cliff
-    assert "carried between iterations: no" in d and "N <= 1048575" not in d and "N <= 1048576" in d and "shard" in d
+    assert "carried between iterations: no" in d and "N <= 1048575 chains" in d and "shard" in d
     assert "carried between iterations: yes" in describe(dense, (1 << 20) - 1)
     assert "plain Leapfrog" in describe(dense, 1000, method=1)
     assert "64 < D <= 128" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
@@ -2513,3 +2513,134 @@ def test_numpy_stream_run_that_dies_hands_back_the_right_rng_state(P, monkeypatc
     np.random.seed(seed)
     s2, _ = hmc.getSamples(3, 1.0 / kB, 1.0)
     assert np.array_equal(s1, s2)
+
+
+# ---------------------------------------------------------------------------------------------
+# GIST: the self-tuning no-U-turn sampler (pbbi_hmc_run_gist) -- a reversible per-chain dynamic length.
+# ---------------------------------------------------------------------------------------------
+def _gist_run(lib, pot, q0, m, h, Lmax, S, flags, seed, iter0, chain0, kT=1.0):
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    D, N = q0.shape
+    qd = as_device(q0, 0, np.float64)
+    md = as_device(m, 0, np.float64) if m is not None else None
+    samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+    reject, ratio, tau = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0), empty((S, 3, N), np.int32, 0)
+    lib.call("pbbi_hmc_run_gist", pot.handle, qd.data_ptr(), md.data_ptr() if m is not None else None,
+             samples.data_ptr(), momenta.data_ptr(), reject.data_ptr(), ratio.data_ptr(), tau.data_ptr(), N, N, h, Lmax,
+             S, flags, seed, iter0, chain0, kT, stream_ptr(0))
+    torch.cuda.synchronize()
+    return (to_numpy(samples), to_numpy(momenta), to_numpy(reject).astype(bool), to_numpy(ratio), to_numpy(tau),
+            to_numpy(qd))
+
+
+@pytest.mark.parametrize("case,mass,draw64", [("diag8", True, False), ("ros12", False, True), ("ros32", True, False),
+                                              ("harm3", False, False)])
+def test_gist_lane_kernels_bitexact_vs_oracle(P, lib, case, mass, draw64):
+    """pbbi_hmc_run_gist on the chain-per-lane kernels (reference operation order): U-turn counts tau_f / tau_b,
+    drawn lengths, decisions, positions and momenta of every iteration equal to oracle_hmc_iter_gist bit for bit."""
+    rs = np.random.RandomState(3)
+    if case == "diag8":
+        D, h = 8, 0.25
+        mu, prec = rs.standard_normal(D), rs.uniform(0.3, 3.0, D)
+        pot, op = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec)
+    elif case == "harm3":
+        D, h = 3, 0.2
+        k = np.array([0.5, 2.0, 9.0])
+        pot, op = P.Harmonic(k), orc.pot_harmonic(k)
+    else:
+        D, h = int(case[3:]), 0.03
+        pot, op = P.Rosenbrock(D), orc.pot_rosenbrock(D)
+    N, S, Lmax, seed, iter0, chain0, kT = 500, 4, 40, 13, 2, 100, 1.0
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    q0 = (1.0 if case.startswith("ros") else 0.0) + 0.5 * rs.standard_normal((D, N))
+    flags = lib.COMPAT_P_FROM_OLDQ | (lib.DRAW_F64 if draw64 else 0)
+    gs, gm, grej, gratio, gtau, gq = _gist_run(lib, pot, q0, m, h, Lmax, S, flags, seed, iter0, chain0, kT)
+    q = np.ascontiguousarray(q0)
+    pstd = np.sqrt((m if mass else np.ones(N)) * kT)
+    n_rej = 0
+    for i in range(S):
+        if draw64:
+            p = orc.philox_normal(seed, orc.STREAM_MOMENTUM | orc.STREAM_DRAW_F64, iter0 + i, chain0, D, N, pstd)
+        else:
+            p = device_normal(lib, seed, lib.STREAM_MOMENTUM, iter0 + i, chain0, D, N, 1.0, pstd)
+        p = np.ascontiguousarray(p)
+        ua = orc.philox_uniform(seed, iter0 + i, chain0, N)
+        ul = orc.philox_steps_uniform(seed, iter0 + i, chain0, N)
+        ratio, rej, tau = orc.hmc_iter_gist(op, q, p, ua, ul, m, h, Lmax)
+        assert np.array_equal(gtau[i], tau), f"iteration {i}"
+        assert np.array_equal(grej[i], rej)
+        assert np.array_equal(gs[i], q) and np.array_equal(gm[i], p)
+        ok = np.isfinite(ratio) & (ratio > 0)
+        assert np.allclose(np.log(gratio[i][ok]), np.log(ratio[ok]), atol=1e-8)
+        n_rej += int(rej.sum())
+    assert np.array_equal(gq, gs[-1])
+    assert 0.05 < n_rej / (S * N) < 0.8
+    assert gtau[:, 0].min() >= 1 and (gtau[:, 1] <= gtau[:, 0]).all() and len(np.unique(gtau[:, 0])) > 3
+
+
+@pytest.mark.parametrize("D,mass", [(128, False), (100, True), (24, False)])
+def test_gist_dense_kernel_vs_oracle(P, lib, D, mass):
+    """... and on the dense MFMA kernel (kick-drift-kick values: a U-turn dot product that passes zero within
+    rounding may be seen one step apart from the oracle; such chains -- none or very few -- are left out)."""
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D))
+    Pm = np.linalg.inv(A @ A.T / D + np.eye(D))
+    Pm = 0.5 * (Pm + Pm.T)
+    pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
+    N, S, Lmax, h, seed = 333, 3, 60, 0.2, 5
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    q0 = rs.standard_normal((D, N))
+    gs, gm, grej, gratio, gtau, _ = _gist_run(lib, pot, q0, m, h, Lmax, S, lib.COMPAT_P_FROM_OLDQ, seed, 0, 0)
+    pstd = np.sqrt(m if mass else np.ones(N))
+    q_start = q0
+    agree = 0
+    for i in range(S):
+        q = np.ascontiguousarray(q_start)
+        p = np.ascontiguousarray(device_normal(lib, seed, lib.STREAM_MOMENTUM, i, 0, D, N, 1.0, pstd))
+        ua, ul = orc.philox_uniform(seed, i, 0, N), orc.philox_steps_uniform(seed, i, 0, N)
+        ratio, rej, tau = orc.hmc_iter_gist(op, q, p, ua, ul, m, h, Lmax)
+        same = (gtau[i] == tau).all(axis=0)
+        with np.errstate(divide="ignore"):
+            clear = np.abs(np.log(ua) - np.minimum(0.0, np.log(np.maximum(ratio, 1e-300)))) > 1e-6
+        ok = same & clear
+        agree += int(same.sum())
+        assert np.array_equal(grej[i][ok], rej[ok])
+        assert scaled_err(gs[i][:, ok], q[:, ok]) <= RTOL_DENSE and scaled_err(gm[i][:, ok], p[:, ok]) <= RTOL_DENSE
+        q_start = gs[i]   # continue from the kernel's own state (a chain left out above would drift apart)
+    assert agree >= 0.98 * S * N
+
+
+def test_gist_samples_a_correlated_gaussian_with_a_resonant_mode(P):
+    """The point of a dynamic length: a target with widely spread frequencies.  One eigen-direction has
+    omega * T = 2 pi for the fixed-length sampler's T -- it comes back to where it started and never mixes (its
+    variance stays at the initial 0.01) -- while GIST, whose lengths follow each chain's own U-turn, recovers the
+    whole covariance within Monte-Carlo error."""
+    D, N = 6, 4096
+    rs = np.random.RandomState(1)
+    Qm, _ = np.linalg.qr(rs.standard_normal((D, D)))
+    h, L = 0.1, 10                                     # fixed-length sampler: T = 1
+    # the LEAPFROG frequency of mode 0 is exactly 2 pi / (L h): cos(w h) = 1 - (h omega)^2 / 2 with w L h = 2 pi
+    omega = np.array([2 * np.sin(np.pi / L) / h, 0.7, 1.3, 2.1, 3.3, 0.4])
+    Pm = (Qm * omega ** 2) @ Qm.T
+    Pm = 0.5 * (Pm + Pm.T)
+    cov = (Qm / omega ** 2) @ Qm.T
+    pot = P.GaussianDense(None, precision=Pm, const=0.0)
+    # fixed length: the resonant direction keeps its initial spread
+    hmc = P.HMC(P.Ensemble(D, N), L * h + 1e-9, h, None, potential=pot, rng="philox", seed=3, verbose=False)
+    s, _ = hmc.getSamples(60, 1.0 / kB, 0.1)
+    z = np.tensordot(Qm[:, 0], s[:, :, 30:], axes=(0, 0))
+    assert abs(z.var() / 0.01 - 1.0) < 0.1             # exactly where it started (qStd^2 = 0.01), not 1/omega^2 = 0.026
+    # GIST
+    hmc = P.HMC(P.Ensemble(D, N), L * h + 1e-9, h, None, potential=pot, rng="philox", seed=3, verbose=False)
+    s, _ = hmc.getSamplesGIST(80, 1.0 / kB, 0.1, max_steps=200)
+    x = s[:, :, 30:].reshape(D, -1)
+    emp = np.cov(x)
+    assert np.max(np.abs(x.mean(axis=1))) < 0.05
+    # in the eigenbasis: every variance within 6 % of 1/omega^2, off-diagonals small
+    C = Qm.T @ emp @ Qm * np.outer(omega, omega)
+    assert np.max(np.abs(np.diag(C) - 1.0)) < 0.06, np.diag(C)
+    assert np.max(np.abs(C - np.diag(np.diag(C)))) < 0.05
+    assert 0.3 < hmc.acceptRate < 0.95
+    tau = hmc.gist_tau
+    assert tau[:, 0].mean() > 5 and tau[:, 0].std() > 1      # lengths really vary chain by chain
