@@ -112,6 +112,7 @@ enum {
     PBBI_DRAW_F64 = 32
 };
 enum { PBBI_STREAM_MOMENTUM = 0, PBBI_STREAM_POSITION = 1, PBBI_STREAM_UNIFORM = 2, PBBI_STREAM_STEPS = 3,
+       PBBI_STREAM_SWAP = 4, /* replica-exchange uniforms (pbbi_replica_exchange) */
        /* OR-ed into pbbi_philox_normal's rng_stream: the draw PBBI_DRAW_F64 selects in pbbi_hmc_run */
        PBBI_STREAM_DRAW_F64 = 0x100 };
 
@@ -289,6 +290,22 @@ int pbbi_hmc_run_gist(const pbbi_potential* pot, void* q_state, const void* mass
                       void* momenta_out, uint8_t* reject_out, void* ratio_out, int32_t* tau_out, int64_t N,
                       int64_t ldn, double h, int Lmax, int S, int flags, uint64_t seed, uint64_t iter0,
                       uint64_t chain0, double kT, void* stream);
+
+/* ---- tempering: replica exchange between temperature rungs ----------------------------
+ * The reference draws momenta at kB*T (src/ensemble.py:88) and plans canonical / micro-canonical ensembles
+ * (references/PhysicsBasedHMC_SoHPC2022_WeekPlan.md:25-27; Ensemble.setWeights, src/ensemble.py:52-61, is
+ * commented out).  A temperature LADDER: the ensemble's N = R*Nr chains form R rungs -- rung r = chains
+ * [r*Nr, (r+1)*Nr), sampled at kT_r by pbbi_hmc_run(..., PBBI_BETA_ACCEPT, kT_r) on its block of the state --
+ * and this call is the exchange step between them, on the device, one launch after the energy evaluation:
+ * for r = parity, parity + 2, ... chain n of rung r and chain n of rung r+1 swap POSITIONS with probability
+ *     min(1, exp((beta_r - beta_{r+1}) (U(q_r) - U(q_{r+1})))),   beta_r = 1 / kT_r,
+ * which leaves prod_r exp(-beta_r U(q_r)) invariant; hot rungs cross barriers, swaps carry the crossings down
+ * to the rung at kT = 1.  betas: R doubles on the DEVICE.  The uniform of a pair is the lower chain's
+ * (global index chain0 + r*Nr + n) draw of PBBI_STREAM_SWAP for `iter`, u53 like the Metropolis uniform.
+ * swapped_out: ((R-1), Nr) bytes or NULL (rows of the other parity are left alone). */
+int pbbi_replica_exchange(const pbbi_potential* pot, void* q, int64_t Nr, int R, int64_t ldn, const double* betas,
+                          int parity, uint64_t seed, uint64_t iter, uint64_t chain0, uint8_t* swapped_out,
+                          void* stream);
 
 /* ---- RNG (device Philox stream) -------------------------------------------
  * out[d*ldn+n] = scale * z(dim d, chain chain0+n); scale_per_chain (N) overrides

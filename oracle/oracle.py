@@ -247,6 +247,21 @@ def hmc_iter_gist(pot, q, p, u_acc, u_len, mass, h, Lmax, compat=COMPAT_P_FROM_O
     return ratio, rej.astype(bool), tau
 
 
+def replica_exchange(pot, q, Nr, R, betas, parity, seed, it, chain0=0):
+    """oracle_replica_exchange in place on q (D, R*Nr); returns the ((R-1), Nr) bool array of swaps (rows of the
+    other parity False)."""
+    st, keep, D = _cpot(pot)
+    Dq, N = _dn(q)
+    assert Dq == D and N == R * Nr
+    betas = np.ascontiguousarray(betas, dtype=np.float64)
+    sw = np.zeros((max(R - 1, 0), Nr), dtype=np.uint8)
+    rc = lib().oracle_replica_exchange(C.byref(st), _ptr(q), C.c_int64(Nr), C.c_int(R), C.c_int64(N), _ptr(betas),
+                                       C.c_int(parity), C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0),
+                                       sw.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return sw.astype(bool)
+
+
 def philox_steps_uniform(seed, it, chain0, N):
     out = np.empty(N)
     lib().oracle_philox_steps_uniform(C.c_uint64(seed), C.c_uint64(it), C.c_uint64(chain0), C.c_int64(N), _ptr(out))

@@ -674,6 +674,34 @@ int oracle_philox_steps(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N
     return 0;
 }
 
+/* Replica exchange between temperature rungs (include/pbbi.h pbbi_replica_exchange; the build's own definition):
+ * rung r = chains [r*Nr, (r+1)*Nr); for r = parity, parity+2, ... chain n of rung r and of rung r+1 swap positions
+ * when u < exp((beta_r - beta_{r+1}) (U_r - U_{r+1})), u = the lower chain's PBBI_STREAM_SWAP (4) uniform. */
+int oracle_replica_exchange(const oracle_pot* P, double* q, int64_t Nr, int R, int64_t ldn, const double* betas,
+                            int parity, uint64_t seed, uint64_t iter, uint64_t chain0, unsigned char* swapped_out) {
+    const int D = P->D;
+    if (D > ORACLE_MAXD) return -1;
+    double* a = (double*)malloc(sizeof(double) * 2 * D);
+    double* b = a + D;
+    for (int r = parity; r + 1 < R; r += 2)
+        for (int64_t n = 0; n < Nr; ++n) {
+            const int64_t lo = (int64_t)r * Nr + n, hi = lo + Nr;
+            col_get(q, D, ldn, lo, a);
+            col_get(q, D, ldn, hi, b);
+            const double arg = (betas[r] - betas[r + 1]) * (pot_U(P, a) - pot_U(P, b));
+            uint32_t x[4];
+            rng_block(seed, 4u, iter, chain0 + (uint64_t)lo, 0xFFFFFFFFu, x);
+            const int swap = u53(x[0], x[1]) < exp(arg);
+            if (swapped_out) swapped_out[(int64_t)r * Nr + n] = (unsigned char)swap;
+            if (swap) {
+                col_put(q, D, ldn, lo, b);
+                col_put(q, D, ldn, hi, a);
+            }
+        }
+    free(a);
+    return 0;
+}
+
 /* the uniform of PBBI_STREAM_STEPS (what PBBI_PER_CHAIN_STEPS and the GIST length draw consume) */
 int oracle_philox_steps_uniform(uint64_t seed, uint64_t iter, uint64_t chain0, int64_t N, double* out) {
     for (int64_t n = 0; n < N; ++n) {

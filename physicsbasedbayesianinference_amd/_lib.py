@@ -20,6 +20,7 @@ PER_CHAIN_STEPS = 8
 UTURN_STOP = 16
 DRAW_F64 = 32            # momenta drawn in double precision (include/pbbi.h)
 STREAM_MOMENTUM, STREAM_POSITION, STREAM_UNIFORM, STREAM_STEPS = 0, 1, 2, 3
+STREAM_SWAP = 4
 STREAM_DRAW_F64 = 0x100  # OR-ed into pbbi_philox_normal's rng_stream: the draw DRAW_F64 selects
 
 
@@ -66,6 +67,7 @@ PROTOTYPES = {
                          _u64, _d, _vp],
     "pbbi_philox_steps": [_u64, _u64, _u64, _i64, _i, _i, _vp, _vp],
     "pbbi_describe_run": [_vp, _i, _i64, _i64, _i, _i, _i, C.c_char_p, _i],
+    "pbbi_replica_exchange": [_vp, _vp, _i64, _i, _i64, _vp, _i, _u64, _u64, _u64, _vp, _vp],
     "pbbi_hmc_run_gist": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64, _u64, _d, _vp],
     "pbbi_hmc_run": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _d, _i, _i, _i, _u64, _u64,
                      _u64, _d, _vp],

@@ -253,6 +253,31 @@ __global__ void k_gist_accept(const T* q_prev, int64_t ld_prev, const T* p_draw,
     if (tau_out) { tau_out[n] = tf; tau_out[N + n] = L; tau_out[2 * N + n] = tb; }
 }
 
+// ---- replica exchange between the temperature rungs of an ensemble (pbbi_replica_exchange) ----------------
+// rung r = chains [r*Nr, (r+1)*Nr).  Pair (r, r+1), r = parity, parity+2, ...: chain n of the one with chain n of
+// the other swap POSITIONS with probability min(1, exp((beta_r - beta_{r+1}) (U_r - U_{r+1}))) -- the Metropolis
+// test that leaves prod_r exp(-beta_r U(q_r)) invariant.  One thread per (pair, n); its uniform is the lower
+// chain's draw of PBBI_STREAM_SWAP.
+template <typename T>
+__global__ void k_replica_exchange(T* q, int64_t ldn, const T* U, const double* betas, int D, int64_t Nr, int R,
+                                   int parity, uint64_t seed, uint64_t iter, uint64_t chain0, uint8_t* swapped) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = parity + 2 * (int)blockIdx.y;
+    if (n >= Nr || r + 1 >= R) return;
+    const int64_t lo = (int64_t)r * Nr + n, hi = lo + Nr;
+    const double a = (betas[r] - betas[r + 1]) * ((double)U[lo] - (double)U[hi]);
+    const PhiloxOut x = rng_block(seed, /*PBBI_STREAM_SWAP*/ 4u, iter, chain0 + (uint64_t)lo, 0xFFFFFFFFu);
+    const double u = u53(x.x0, x.x1);
+    const bool swap = u < exp(a);   // NaN energies: no swap
+    if (swapped) swapped[(int64_t)r * Nr + n] = swap ? 1 : 0;
+    if (swap)
+        for (int d = 0; d < D; ++d) {
+            const T t = q[(int64_t)d * ldn + lo];
+            q[(int64_t)d * ldn + lo] = q[(int64_t)d * ldn + hi];
+            q[(int64_t)d * ldn + hi] = t;
+        }
+}
+
 // (S, D*N) -> (D*N, S) tiled transpose through LDS: both sides coalesced.
 template <typename T>
 __global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int S, int64_t M) {
@@ -973,6 +998,36 @@ int pbbi_hmc_run_gist(const pbbi_potential* pot, void* q_state, const void* mass
                                 Lmax, S, flags, seed, iter0, chain0, kT, (hipStream_t)stream);
     return gist_run<float>(pot, q_state, mass, samples_out, momenta_out, reject_out, ratio_out, tau_out, N, ldn, h, Lmax,
                            S, flags, seed, iter0, chain0, kT, (hipStream_t)stream);
+}
+
+int pbbi_replica_exchange(const pbbi_potential* pot, void* q, int64_t Nr, int R, int64_t ldn, const double* betas,
+                          int parity, uint64_t seed, uint64_t iter, uint64_t chain0, uint8_t* swapped_out,
+                          void* stream) {
+    if (!pot) return pbbi_fail(PBBI_ERR_INVALID, "potential handle is NULL");
+    if (R < 1 || Nr < 0) return pbbi_fail(PBBI_ERR_INVALID, "need R >= 1 rungs of Nr >= 0 chains");
+    const int64_t N = (int64_t)R * Nr;
+    if (int rc = check_common(pot, N, ldn)) return rc;
+    if (parity != 0 && parity != 1) return pbbi_fail(PBBI_ERR_INVALID, "parity must be 0 or 1");
+    if (iter > UINT32_MAX) return pbbi_fail(PBBI_ERR_INVALID, "iter must be < 2^32");
+    if (N == 0 || R < 2 || parity + 1 >= R) return PBBI_OK;
+    if (!q || !betas) return pbbi_fail(PBBI_ERR_INVALID, "q / betas is NULL");
+    DeviceGuard guard(pot->device);
+    hipStream_t st = (hipStream_t)stream;
+    Scratch ws(st);
+    void* U = ws.get((size_t)N * elem_size(pot->dtype));
+    if (!U) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the potential energies");
+    EvalArgs e{pot, q, nullptr, nullptr, N, ldn, U, nullptr, nullptr, 0, st};
+    if (int rc = route_eval(e)) return rc;
+    const int pairs = (R - parity) / 2;
+    const dim3 grid((unsigned)((Nr + 255) / 256), (unsigned)pairs), block(256);
+    if (pot->dtype == PBBI_F64)
+        hipLaunchKernelGGL(k_replica_exchange<double>, grid, block, 0, st, (double*)q, ldn, (const double*)U, betas,
+                           pot->D, Nr, R, parity, seed, iter, chain0, swapped_out);
+    else
+        hipLaunchKernelGGL(k_replica_exchange<float>, grid, block, 0, st, (float*)q, ldn, (const float*)U, betas,
+                           pot->D, Nr, R, parity, seed, iter, chain0, swapped_out);
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
 }
 
 // what pbbi_hmc_run would do with these arguments, in words (include/pbbi.h)

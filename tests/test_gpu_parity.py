@@ -2644,3 +2644,103 @@ def test_gist_samples_a_correlated_gaussian_with_a_resonant_mode(P):
     assert 0.3 < hmc.acceptRate < 0.95
     tau = hmc.gist_tau
     assert tau[:, 0].mean() > 5 and tau[:, 0].std() > 1      # lengths really vary chain by chain
+
+
+# ---------------------------------------------------------------------------------------------
+# Tempering that uses the temperature: replica exchange between rungs (pbbi_replica_exchange, tempering.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,parity", [(4, 0), (4, 1), (5, 0), (5, 1), (2, 0), (1, 0)])
+def test_replica_exchange_kernel_vs_oracle(P, lib, R, parity):
+    """The device exchange step against oracle_replica_exchange on the same state: the same pairs swap, the
+    state afterwards is the same bit for bit, untouched rungs stay untouched (potentials whose evaluation kernel
+    is bit-exact with the oracle: diagonal Gaussian)."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, stream_ptr, to_numpy
+    D, Nr, seed, it, chain0 = 5, 777, 31, 9, 2 ** 33
+    rs = np.random.RandomState(R * 2 + parity)
+    mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2.0, D)
+    pot, op = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec)
+    kTs = 1.7 ** np.arange(R)
+    q0 = rs.standard_normal((D, R * Nr)) * np.repeat(np.sqrt(kTs), Nr)[None, :]
+    qd = as_device(q0, 0, np.float64)
+    betas = as_device(1.0 / kTs, 0, np.float64)
+    sw = torch.zeros((max(R - 1, 1), Nr), dtype=torch.uint8, device="cuda")
+    lib.call("pbbi_replica_exchange", pot.handle, qd.data_ptr(), Nr, R, R * Nr, betas.data_ptr(), parity, seed, it,
+             chain0, sw.data_ptr(), stream_ptr(0))
+    torch.cuda.synchronize()
+    q_or = np.ascontiguousarray(q0)
+    sw_or = orc.replica_exchange(op, q_or, Nr, R, 1.0 / kTs, parity, seed, it, chain0)
+    assert np.array_equal(to_numpy(qd), q_or)
+    if R > 1:
+        assert np.array_equal(to_numpy(sw)[:R - 1].astype(bool), sw_or)
+        if parity + 1 < R:
+            assert 0.2 < sw_or[parity::2].mean() < 0.95      # some pairs swap, some do not
+        assert not sw_or[1 - parity::2].any()
+    else:
+        assert np.array_equal(to_numpy(qd), q0)
+
+
+def test_tempering_ladder_recovers_both_modes_of_a_bimodal_target(P):
+    """A 2-D mixture 0.7 N((-4, 0), 0.6^2) + 0.3 N((+4, 0), 0.6^2), written as a Python callable on the traceable
+    namespace: a barrier of ~22 kT between the modes.  Started symmetrically, a single-temperature ensemble keeps
+    half its chains in each mode for ever (weight 0.5); the ladder's rung 0 recovers the weights 0.7 / 0.3 within
+    3 %, with the right within-mode spread."""
+    from physicsbasedbayesianinference_amd import trace as jnp
+    from physicsbasedbayesianinference_amd.tempering import TemperingLadder, geometric_ladder
+    a, b, sig, wa = np.array([-4.0, 0.0]), np.array([4.0, 0.0]), 0.6, 0.7
+
+    def potential(q):
+        la = np.log(wa) - 0.5 * jnp.sum((q - a) ** 2) / sig ** 2
+        lb = np.log(1.0 - wa) - 0.5 * jnp.sum((q - b) ** 2) / sig ** 2
+        return -jnp.logaddexp(la, lb)
+    Nr = 4096
+    # one temperature: the modes never exchange chains
+    hmc = P.HMC(P.Ensemble(2, Nr), 1.0, 0.1, None, potential=potential, rng="philox", seed=5, verbose=False)
+    s, _ = hmc.getSamples(120, 1.0 / kB, 4.0)
+    left0 = (s[0, :, 0] < 0).mean()
+    left = (s[0, :, 60:] < 0).mean()
+    assert abs(left - left0) < 0.02 and abs(left - wa) > 0.1            # stuck at the initial split
+    # the ladder
+    ladder = TemperingLadder(potential, 2, Nr, geometric_ladder(40.0, 7), simulTime=1.0, stepSize=0.1, seed=5)
+    x = ladder.run(numSamples=60, qStd=4.0, swap_every=2, burn_in=500)
+    assert x.shape == (2, Nr, 60)
+    w_left = (x[0] < 0).mean()
+    assert abs(w_left - wa) < 0.03, w_left
+    for mode, sel in ((a, x[0] < 0), (b, x[0] >= 0)):
+        pts = x[:, sel]
+        assert np.max(np.abs(pts.mean(axis=1) - mode)) < 0.05
+        assert np.max(np.abs(pts.std(axis=1) - sig)) < 0.05
+    assert ladder.swapRates.shape == (6,) and ladder.swapRates.min() > 0.1
+    assert ladder.acceptRates.min() > 0.5
+    # rungs in between sample exp(-U / kT): the hot rung's spread within a mode is sig * sqrt(kT)
+    both = ladder.run(numSamples=20, qStd=4.0, swap_every=2, burn_in=200, record_rungs=(0, 3))
+    hot = both[3]
+    kT3 = ladder.kTs[3]
+    assert abs(hot[1].std() / (sig * np.sqrt(kT3)) - 1.0) < 0.1
+
+
+def test_eight_schools_hierarchical_model(P):
+    """The reference's hierarchical example (samples/NumpyroExamples/eight_schools.py, its data file) as a traced
+    potential.  Parity unpinned: NumPyro is not importable here and the reference records no posterior, so the
+    check is (a) the two parametrisations -- different potentials, different geometry -- agree on the posterior of
+    (mu, tau, theta), and (b) the classic summaries of this data set (Gelman et al., BDA3 5.5: E[mu] ~ 4.4,
+    E[tau] ~ 3.6, shrunken school effects between 3 and 7)."""
+    from physicsbasedbayesianinference_amd.models import eight_schools_constrain, eight_schools_potential
+    N = 8192
+    post = {}
+    for centered, (T, h, S, B) in ((False, (1.0, 0.05, 60, 150)), (True, (1.5, 0.015, 200, 400))):
+        pot = eight_schools_potential(centered=centered)
+        hmc = P.HMC(P.Ensemble(10, N), T, h, None, potential=pot, rng="philox", seed=2, verbose=False, kdk_fma=False)
+        assert hmc._pot.kind == "custom"
+        s, _ = hmc.getSamples(S, 1.0 / kB, 1.0, burn_in=B)
+        assert hmc.acceptRate > 0.6
+        post[centered] = eight_schools_constrain(s, centered)
+    nc = post[False]
+    assert abs(nc["mu"].mean() - 4.4) < 0.4 and abs(nc["tau"].mean() - 3.6) < 0.5
+    th = nc["theta"].mean(axis=(1, 2))
+    assert th.min() > 2.5 and th.max() < 8.0 and th.argmax() == 0            # school A keeps the largest effect
+    # the centred run (funnel: slower, only loosely converged) tells the same story
+    c = post[True]
+    assert abs(c["mu"].mean() - nc["mu"].mean()) < 0.6
+    assert abs(np.median(c["tau"]) - np.median(nc["tau"])) < 1.0
+    assert np.max(np.abs(c["theta"].mean(axis=(1, 2)) - th)) < 1.0
