@@ -2738,7 +2738,8 @@ def test_eight_schools_hierarchical_model(P):
     nc = post[False]
     assert abs(nc["mu"].mean() - 4.4) < 0.4 and abs(nc["tau"].mean() - 3.6) < 0.5
     th = nc["theta"].mean(axis=(1, 2))
-    assert th.min() > 2.5 and th.max() < 8.0 and th.argmax() == 0            # school A keeps the largest effect
+    # shrunken school effects: every one between 3 and 7, schools A and G (y = 28, 18) on top, E (y = -1) lowest
+    assert th.min() > 2.5 and th.max() < 8.0 and set(np.argsort(th)[-2:]) == {0, 6} and th.argmin() == 4
     # the centred run (funnel: slower, only loosely converged) tells the same story
     c = post[True]
     assert abs(c["mu"].mean() - nc["mu"].mean()) < 0.6
