@@ -461,26 +461,27 @@ def bench_c2(args, rank, world, local_rank):
         gathered_bytes = blk.blocks.numel() * 8
         del blk
 
-        def chunks(og):
+        og = OverlappedGather((c, D, N), torch.float64, f"cuda:{dev}", N * world)
+
+        def chunks(gather):
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
             for k in range(n_chunks):
-                buf = og.local(k) if og is not None else samples[(k & 1) * c:(k & 1) * c + c]
+                buf = og.local(k)                    # the same two slab buffers with and without the collection
                 _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q_state.data_ptr(), None, buf.data_ptr(),
                           None, reject.data_ptr(), None, N, N, STEP, L, c, run_flags, seed, 10 ** 6 + k * c,
                           chain0, 1.0, stream)
-                if og is not None:
+                if gather:
                     og.submit(k, c)
-            if og is not None:
+            if gather:
                 og.finish()
             torch.cuda.synchronize()
             barrier()
             return reduce_max(time.perf_counter() - t0)
-        og = OverlappedGather((c, D, N), torch.float64, f"cuda:{dev}", N * world)
-        chunks(og)                                   # (first use: communicator / buffer warm-up)
-        t_over = chunks(og)
-        t_plain = chunks(None)
+        chunks(True)                                 # (first use: communicator / buffer warm-up)
+        t_over = chunks(True)
+        t_plain = chunks(False)
         collect = {"allgather_ms": allgather_s * 1e3, "allgather_bytes_received_per_rank": gathered_bytes,
                    "allgather_GBs_per_rank": gathered_bytes / allgather_s / 1e9,
                    "overlapped": {"chunks": n_chunks, "iterations_per_chunk": c,
