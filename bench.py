@@ -307,6 +307,49 @@ def bench_stream(args):
                              traffic=None, design_traffic_GBs=design / ks / 1e9, launch_ms=ks * 1e3)}
 
 
+def bench_dense(args):
+    """Extra: a dense-precision Gaussian at any D (fp64): the register-resident MFMA kernel up to D = 128, the
+    GEMM path beyond.  The executed mat-vec count comes from pbbi_describe_run (carried gradient or not)."""
+    import ctypes
+    import torch
+    import physicsbasedbayesianinference_amd as P
+    from physicsbasedbayesianinference_amd import _lib
+    d, N, h, L = args.dim, args.chains, STEP, int(SIMUL / STEP)
+    K, W = args.steps, args.warmup
+    pot = P.GaussianDense(None, precision=precision_matrix(d), const=0.0)
+    stream = torch.cuda.current_stream().cuda_stream
+    q = torch.empty((d, N), dtype=torch.float64, device="cuda")
+    _lib.call("pbbi_philox_normal", 7, _lib.STREAM_POSITION, 0, 0, d, N, N, 1.0, None, _lib.F64, 0, q.data_ptr(), stream)
+    S_alloc = max(K, 1)
+    samples = torch.empty((S_alloc, d, N), dtype=torch.float64, device="cuda")
+    momenta = torch.empty((S_alloc, d, N), dtype=torch.float64, device="cuda")
+    reject = torch.empty((S_alloc, N), dtype=torch.uint8, device="cuda")
+
+    def run(S, it0):
+        while S > 0:
+            s = min(S, S_alloc)
+            _lib.call("pbbi_hmc_run", pot.handle, _lib.LEAPFROG, q.data_ptr(), None, samples.data_ptr(),
+                      momenta.data_ptr(), reject.data_ptr(), None, N, N, h, L, s, 1, 7, it0, 0, 1.0, stream)
+            S, it0 = S - s, it0 + s
+    (t, ev), (ts, evs) = timed_runs(run, K, W, max(W + K, SETTLE))
+    buf = ctypes.create_string_buffer(1024)
+    _lib.call("pbbi_describe_run", pot.handle, _lib.LEAPFROG, N, N, L, K, 1, buf, len(buf))
+    route = buf.value.decode()
+    carried = "carried between iterations: yes" in route
+    ks, kss = ev * 1e-3 / K, evs * 1e-3 / K
+    flops_alg = flops_per_step_chain(d, L) * L * N
+    flops_exec = (2.0 * d * d * ((L + 1.0 / K) if carried else L + 1) + 11.0 * d * L + 8.0 * d) * N
+    return {
+        "metric": f"leapfrog-steps*chains/sec; dense Gaussian d={d}, ensemble={N}, f64",
+        "value": K * L * N / t, "value_steady": K * L * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K,
+        "warmup": W, "ms_per_step": t * 1e3 / K, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"dense precision d={d}, {N} chains, L={L}, h={h}", "route": route,
+                   "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
+        "roofline": roofline("mfma", route.split(";")[0], FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", ks, kss, flops_exec,
+                             flops_alg, "the gradient mat-vecs performed (see config.route) + updates + energies, "
+                             "counted at the true D (rows padded to the kernel's tile are not work)", traffic=None)}
+
+
 def bench_c5(args):
     """BASELINE config 5: d=4096 dense-precision Gaussian, 8192 chains, fp32, h=0.05, L=10:
     L+1 fused MFMA GEMMs per HMC iteration (kernels_big.hip).  MFMA-bound."""
@@ -586,12 +629,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1: skip the C3 / C5 lines embedded under other_workloads")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "stream", "parity"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "stream", "parity", "dense"],
                     help="c2 (default, the BASELINE metric, with C3/C5 embedded at N = 1); c3 / c5 / "
                          "stream / parity print that workload's own line")
     ap.add_argument("--exact-order", action="store_true",
                     help="--workload c3 / stream: the bit-exact velocity-Verlet kernels instead of PBBI_KDK_FMA")
-    ap.add_argument("--dim", type=int, default=128, help="--workload stream: dimension")
+    ap.add_argument("--dim", type=int, default=128, help="--workload stream / dense: dimension")
     ap.add_argument("--potential", default="rosenbrock", choices=["rosenbrock", "diag"],
                     help="--workload stream: potential")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="--workload stream")
@@ -609,7 +652,7 @@ def main():
         ap.error("--steps >= 1, --warmup >= 0, --gpus >= 1")
 
     if args.workload != "c2":
-        fn = {"c3": lambda: bench_c3(args, args.exact_order), "c5": lambda: bench_c5(args),
+        fn = {"c3": lambda: bench_c3(args, args.exact_order), "c5": lambda: bench_c5(args), "dense": lambda: bench_dense(args),
               "stream": lambda: bench_stream(args), "parity": lambda: bench_parity(args)}[args.workload]
         print(json.dumps(fn()))
         return 0
