@@ -223,6 +223,26 @@ __device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t base, uint32_t
     }
 }
 
+// k_dense_hmc's accessors: no guards at all.  For D < DP the state arrays are addressed through BOUNDED
+// descriptors (pbbi_buf.h::buf_make_rows: num_records ends at the array's last element), so a load of a row
+// d >= D returns 0 and a store to it is dropped by the hardware's range check -- the row guards of
+// load_elem / store_elem above cost the fused kernel > 100 spilled registers (phi copies of the state arrays
+// around every branch), which is why padded D used to run unfused.
+__device__ __forceinline__ double load_row(__amdgpu_buffer_rsrc_t base, uint32_t voff, uint32_t stride4, int s) {
+    return buf_load<double>(base, voff, (uint32_t)s * stride4);
+}
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t base, uint32_t voff, uint32_t stride4, int s,
+                                          double val) {
+    buf_store(base, voff, (uint32_t)s * stride4, val);
+}
+// descriptor of a (D, N)-shaped array (leading stride ld) seen from chain n0: unbounded when D == DP
+template <bool FULL>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_of(const double* arr, int64_t n0, int D, int64_t ld,
+                                                          int64_t N) {
+    if constexpr (FULL) return buf_make(arr + n0);
+    return buf_make_rows(arr + n0, D, ld, N, n0, 8);
+}
+
 template <int NT, int METHOD, bool FULL>
 __global__ void __launch_bounds__(BLOCK, 1) k_dense_traj(DensePrm prm) {
     constexpr int DP = 16 * NT;
@@ -583,9 +603,9 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     const uint32_t ld_in = 8u * (uint32_t)prm.ldn_in, ld_out = 8u * (uint32_t)prm.ldn_out;
     const uint32_t vin = (uint32_t)g * ld_in + 8u * (uint32_t)cc, s4in = 4u * ld_in;
     const uint32_t vout = (uint32_t)g * ld_out + 8u * (uint32_t)cc, s4out = 4u * ld_out;
-    const __amdgpu_buffer_rsrc_t qin = buf_make(prm.q_in + n0);
-    const __amdgpu_buffer_rsrc_t qout = buf_make(prm.q_out + n0);
-    const __amdgpu_buffer_rsrc_t pout = buf_make(prm.p_out + n0);
+    const __amdgpu_buffer_rsrc_t qin = rows_of<FULL>(prm.q_in, n0, D, prm.ldn_in, prm.N);
+    const __amdgpu_buffer_rsrc_t qout = rows_of<FULL>(prm.q_out, n0, D, prm.ldn_out, prm.N);
+    const __amdgpu_buffer_rsrc_t pout = rows_of<FULL>(prm.p_out, n0, D, prm.ldn_out, prm.N);
     const double m = prm.mass ? prm.mass[n0 + cc] : 1.0;
     const double minv = prm.mass ? 1.0 / m : 1.0;
     const bool rng = (MODE == 0) && prm.rng;
@@ -600,7 +620,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     double q[KS];
     if constexpr (FUSE) {  // the chain's position stays in these registers for the whole launch
 #pragma unroll
-        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+        for (int s = 0; s < KS; ++s) q[s] = load_row(qin, vin, s4in, s);
     }
     // FUSE: prm.fuse_S consecutive iterations of the run in this launch (the host passes ldn_in == ldn_out:
     // every iteration after a run's first reads the previous position slab).  Iteration kf draws with
@@ -622,7 +642,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
 #pragma unroll
                 for (int t = 0; t < NTP; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) store_elem<FULL>(gbuf, vg0, s4g, 4 * t + r, g, D, acc0[t][r]);
+                    for (int r = 0; r < 4; ++r) store_row(gbuf, vg0, s4g, 4 * t + r, acc0[t][r]);
             }
             if constexpr (NPASS == 2) {
                 matvec_pass<NT, NTP, 1, false, ZMEAN>(fragL, muG, q, q, acc0, h);
@@ -631,7 +651,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
                     for (int t = 0; t < NTP; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            store_elem<FULL>(gbuf, vg0, s4g, 4 * (NTP + t) + r, g, D, acc0[t][r]);
+                            store_row(gbuf, vg0, s4g, 4 * (NTP + t) + r, acc0[t][r]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -646,9 +666,9 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     if constexpr (FUSE) {
         const int64_t s_out = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf) & 1) : prm.fuse_slab0 + kf;
         const int64_t s_prev = prm.fuse_wrap2 ? ((prm.fuse_slab0 + kf - 1) & 1) : prm.fuse_slab0 + kf - 1;
-        if (kf > 0) qin_k = buf_make(prm.fuse_q_base + s_prev * prm.fuse_slab + n0);
-        qout_k = buf_make(prm.fuse_q_base + s_out * prm.fuse_slab + n0);
-        pout_k = buf_make(prm.p_out + (prm.p_out ? (int64_t)kf * prm.fuse_slab : 0) + n0);
+        if (kf > 0) qin_k = rows_of<FULL>(prm.fuse_q_base + s_prev * prm.fuse_slab, n0, D, prm.ldn_out, prm.N);
+        qout_k = rows_of<FULL>(prm.fuse_q_base + s_out * prm.fuse_slab, n0, D, prm.ldn_out, prm.N);
+        pout_k = rows_of<FULL>(prm.p_out + (prm.p_out ? (int64_t)kf * prm.fuse_slab : 0), n0, D, prm.ldn_out, prm.N);
     }
     if constexpr (CARRY != 0) {
         const uint32_t vg0 = (uint32_t)g * ld_g + 8u * (uint32_t)cc;
@@ -666,7 +686,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         for (int t = 0; t < NTP; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[t][r] = load_elem<FULL>(gbuf, vg_cur, s4g, ld_g, 4 * (PASS * NTP + t) + r, g, D);
+                acc[t][r] = load_row(gbuf, vg_cur, s4g, 4 * (PASS * NTP + t) + r);
     };
     auto carry_store = [&](auto pass_c, uint32_t voff) {
         constexpr int PASS = decltype(pass_c)::value;
@@ -675,7 +695,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
             for (int t = 0; t < NTP; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    store_elem<FULL>(gbuf, voff, s4g, 4 * (PASS * NTP + t) + r, g, D, acc[t][r]);
+                    store_row(gbuf, voff, s4g, 4 * (PASS * NTP + t) + r, acc[t][r]);
         }
     };
     using P0 = std::integral_constant<int, 0>;
@@ -699,17 +719,17 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
             // non-compat: a rejected chain reports its drawn momentum; park the draw in the slab
             // now (accepted chains overwrite it below) rather than regenerate it later.
 #pragma unroll
-            for (int s = 0; s < KS; ++s) store_elem<FULL>(pout_k, vout, s4out, s, g, D, vh[s]);
+            for (int s = 0; s < KS; ++s) store_row(pout_k, vout, s4out, s, vh[s]);
         }
     } else {
-        const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
+        const __amdgpu_buffer_rsrc_t pin = rows_of<FULL>(prm.p_in, n0, D, prm.ldn_in, prm.N);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
+        for (int s = 0; s < KS; ++s) vh[s] = load_row(pin, vin, s4in, s);
     }
     STAMP(2);
     if constexpr (!FUSE) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin, vin, s4in, ld_in, s, g, D);
+        for (int s = 0; s < KS; ++s) q[s] = load_row(qin, vin, s4in, s);
     }
     __builtin_amdgcn_sched_barrier(0);
     double pp = 0.0;
@@ -770,7 +790,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
             constexpr int PASS = decltype(pass_c)::value;
             double q0r[4 * NTP];
 #pragma unroll
-            for (int t = 0; t < 4 * NTP; ++t) q0r[t] = load_elem<FULL>(qin_k, vin, s4in, ld_in, 4 * PASS * NTP + t, g, D);
+            for (int t = 0; t < 4 * NTP; ++t) q0r[t] = load_row(qin_k, vin, s4in, 4 * PASS * NTP + t);
             double sum = 0.0;
 #pragma unroll
             for (int t = 0; t < NTP; ++t)
@@ -848,16 +868,16 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     // vh = final velocity, xg = x . g at the final position
 
     if constexpr (MODE == 1) {  // integrate(): in place q, p; optional Integrator.v
-        const __amdgpu_buffer_rsrc_t vout_p = buf_make(prm.v_out + n0);
+        const __amdgpu_buffer_rsrc_t vout_p = rows_of<FULL>(prm.v_out, n0, D, prm.ldn_out, prm.N);
         if (valid) {
             if (prm.v_out) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) store_elem<FULL>(vout_p, vout, s4out, s, g, D, vh[s]);
+                for (int s = 0; s < KS; ++s) store_row(vout_p, vout, s4out, s, vh[s]);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                store_elem<FULL>(qout, vout, s4out, s, g, D, q[s]);
-                store_elem<FULL>(pout, vout, s4out, s, g, D, vh[s] * m);  // p = v*m (:119)
+                store_row(qout, vout, s4out, s, q[s]);
+                store_row(pout, vout, s4out, s, vh[s] * m);  // p = v*m (:119)
             }
         }
     } else {
@@ -878,24 +898,24 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
         bool store_p = (prm.p_out != nullptr);
         if (reject) {  // rare: fetch the old point again instead of keeping it in registers
 #pragma unroll
-            for (int s = 0; s < KS; ++s) q[s] = load_elem<FULL>(qin_k, vin, s4in, ld_in, s, g, D);  // :175
+            for (int s = 0; s < KS; ++s) q[s] = load_row(qin_k, vin, s4in, s);  // :175
             if (compat) {  // :176  p <- oldQ
 #pragma unroll
                 for (int s = 0; s < KS; ++s) vh[s] = q[s];
             } else if (rng) {
                 store_p = false;  // the draw parked in the slab stays
             } else if (store_p) {
-                const __amdgpu_buffer_rsrc_t pin = buf_make(prm.p_in + n0);
+                const __amdgpu_buffer_rsrc_t pin = rows_of<FULL>(prm.p_in, n0, D, prm.ldn_in, prm.N);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) vh[s] = load_elem<FULL>(pin, vin, s4in, ld_in, s, g, D);
+                for (int s = 0; s < KS; ++s) vh[s] = load_row(pin, vin, s4in, s);
             }
         }
         if (valid) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) store_elem<FULL>(qout_k, vout, s4out, s, g, D, q[s]);  // :178
+            for (int s = 0; s < KS; ++s) store_row(qout_k, vout, s4out, s, q[s]);  // :178
             if (store_p) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) store_elem<FULL>(pout_k, vout, s4out, s, g, D, vh[s]);  // :179
+                for (int s = 0; s < KS; ++s) store_row(pout_k, vout, s4out, s, vh[s]);  // :179
             }
         }
         if constexpr (CARRY != 0) csel ^= reject ? 0u : 1u;  // accepted: the other slab is current now
@@ -1035,26 +1055,33 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
+        constexpr bool CARRYK = (NT_ == 8 || NT_ == 4) && M_ == 0;   /* carried / fused forms exist */ \
+        constexpr int NTC = CARRYK ? NT_ : 8;                                                     \
+        constexpr bool HEAD = (NT_ == 8) && F_;   /* the C2 shape: draw specialised at compile time */ \
         if (dyn && M_ == 0) {                                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>), grid2, block2, lds, \
                                stream, prm);                                                      \
-        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && carry == 1) {                            \
-            if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>, lds)) return rc; \
-            hipLaunchKernelGGL((k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 1>), grid2, block2, lds, \
+        } else if (method == PBBI_LEAPFROG && CARRYK && carry == 1) {                             \
+            if (int rc = set_lds(k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 1>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 1>), grid2, block2, lds, \
                                stream, prm);                                                      \
-        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && F_ && carry == 2 && prm.fuse_S > 1 &&   \
+        } else if (method == PBBI_LEAPFROG && CARRYK && carry == 2 && prm.fuse_S > 1 && HEAD &&   \
                    (prm.flags & PBBI_DRAW_F64)) {                                                 \
             if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 1>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 1>), grid2, block2, lds, \
                                stream, prm);                                                      \
-        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && F_ && carry == 2 && prm.fuse_S > 1) {   \
+        } else if (method == PBBI_LEAPFROG && CARRYK && carry == 2 && prm.fuse_S > 1 && HEAD) {   \
             if (int rc = set_lds(k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 0>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<8, true, 0, Z_, PBBI_LEAPFROG, false, 2, true, 0>), grid2, block2, lds, \
                                stream, prm);                                                      \
-        } else if (method == PBBI_LEAPFROG && M_ == 0 && NT_ == 8 && carry == 2) {                            \
-            if (int rc = set_lds(k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 2>, lds)) return rc; \
-            hipLaunchKernelGGL((k_dense_hmc<8, F_, 0, Z_, PBBI_LEAPFROG, false, 2>), grid2, block2, lds, \
+        } else if (method == PBBI_LEAPFROG && CARRYK && carry == 2 && prm.fuse_S > 1) {           \
+            if (int rc = set_lds(k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2, true, 2>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2, true, 2>), grid2, block2, lds, \
+                               stream, prm);                                                      \
+        } else if (method == PBBI_LEAPFROG && CARRYK && carry == 2) {                             \
+            if (int rc = set_lds(k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2>), grid2, block2, lds, \
                                stream, prm);                                                      \
         } else if (method == PBBI_LEAPFROG) {                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>, lds)) return rc;    \
@@ -1193,7 +1220,7 @@ int dense_hmc_iter(const IterArgs& a) {
         carry = a.carry;
         prm.carry_g = (double*)a.carry_g;
         prm.carry_sel = a.carry_sel;
-        prm.carry_slab_bytes = (uint32_t)((uint64_t)a.pot->D * (uint64_t)a.N * 8u);
+        prm.carry_slab_bytes = (uint32_t)((uint64_t)a.pot->DP * (uint64_t)a.N * 8u);  // slabs hold the padded rows too
     }
     if (a.fuse_S > 1) {
         if (carry == 0 || a.ldn_in != a.ldn_out || !a.rng)
@@ -1219,19 +1246,19 @@ int dense_fused_iterations(const IterArgs& a) {
         const int v = e ? atoi(e) : 64;
         return v < 1 ? 1 : v;
     }();
-    if (a.carry == 0 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a) ||
-        a.pot->D != a.pot->DP)  // (the padded-D instantiations of the fused form spill: not built)
+    if (a.carry == 0 || !a.carry_g || !a.carry_sel || !a.rng || a.ldn_in != a.ldn_out || !dense_carry_applies(a))
         return 1;
     return chunk;
 }
 
 // May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Plain
-// Leapfrog on the two-wave kernel at 64 < D <= 128 (the instantiations that exist: each costs ~10 s of
-// build time), both slabs addressable with 32-bit offsets.
+// Leapfrog on the two-wave kernel at 32 < D <= 128 (padded D included: DP = 64 or 128), both slabs -- DP rows
+// each -- addressable with 32-bit offsets.
 bool dense_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
-    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP == 128 && a.N > 0 &&
-           (uint64_t)a.pot->D * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) && getenv("PBBI_DENSE_V1") == nullptr;
+    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && (a.pot->DP == 128 || a.pot->DP == 64) &&
+           a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) &&
+           getenv("PBBI_DENSE_V1") == nullptr;
 }
 
 int dense_integrate(const IntegrateArgs& a) {

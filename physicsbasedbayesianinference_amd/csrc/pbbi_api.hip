@@ -900,7 +900,8 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     // dense MFMA kernel: the gradient at the chain's position is carried from one iteration to the next
     // (two (D, N) slabs + one byte per chain, kernels_dense.hip CARRY) -- L mat-vecs per iteration, not L + 1
     char* carry = nullptr;
-    size_t carry_bytes = 2 * slab * sizeof(double), sel_bytes = (size_t)N;
+    // (the dense path's slabs hold the PADDED rows: DP x N each)
+    size_t carry_bytes = 2 * (size_t)(pot->DP ? pot->DP : pot->D) * (size_t)N * sizeof(double), sel_bytes = (size_t)N;
     bool use_carry = false;
     if (S >= 2 && pot->kind != KIND_CUSTOM && (is_dense(pot) || is_big(pot))) {
         IterArgs probe{};
@@ -1056,13 +1057,13 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
             d += "; gradient carried between iterations: yes (L mat-vecs per iteration)";
         } else {
             d += "; gradient carried between iterations: no (L + 1 mat-vecs per iteration) -- ";
-            const uint64_t lim = (((uint64_t)1 << 31) - 1) / ((uint64_t)pot->D * 16u);
+            const uint64_t lim = (((uint64_t)1 << 31) - 1) / ((uint64_t)pot->DP * 16u);
             if (S < 2) d += "a run of one iteration";
             else if (method != PBBI_LEAPFROG || L < 1 || pbbi_dyn(a)) d += "plain Leapfrog runs with L >= 1 only";
-            else if (pot->DP != 128) d += "the carried form exists for 64 < D <= 128";
+            else if (pot->DP != 128 && pot->DP != 64) d += "the carried form exists for 32 < D <= 128";
             else if ((uint64_t)N > lim)
                 d += "the two carried-gradient slabs (D*N*16 bytes) must stay below 2^31 for 32-bit buffer offsets: "
-                     "at D = " + std::to_string(pot->D) + " that is N <= " + std::to_string(lim) +
+                     "at D = " + std::to_string(pot->D) + " (rows padded to " + std::to_string(pot->DP) + ") that is N <= " + std::to_string(lim) +
                      " chains per call; shard the ensemble or split the call";
             else d += "switched off (PBBI_NO_CARRY / PBBI_DENSE_V1)";
         }

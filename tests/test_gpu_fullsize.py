@@ -289,9 +289,13 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
 
 
 @pytest.mark.parametrize("D,zero_mean,mass,compat", [(128, True, False, True), (128, False, True, False),
-                                                     (100, False, True, False), (65, True, True, True)])
+                                                     (100, False, True, False), (65, True, True, True),
+                                                     (100, True, False, True), (64, True, False, True),
+                                                     (64, False, True, False), (48, True, True, True),
+                                                     (33, False, False, False)])
 def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
-    """pbbi_hmc_run on the dense kernel at 64 < D <= 128 keeps the gradient of the chain's position between
+    """pbbi_hmc_run on the dense kernel at 32 < D <= 128 (round 3: padded D and D <= 64 too, fused launches
+    included -- rows d >= D are handled by bounded buffer descriptors, not guards) keeps the gradient of the chain's position between
     iterations (kernels_dense.hip CARRY: accepted chains take g(q_new) of the previous launch, rejected
     ones the gradient they started from) instead of forming it again.  One run of S iterations must equal
     S runs of one iteration (which cannot carry anything) bit for bit -- samples, momenta, ratios and
