@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(BLOCK2, 2) k_dense_hmc(DensePrm prm) {
     static_assert(!FUSE || CARRY == 2, "a fused launch reads the carried gradient (its first iteration may form it)");
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
-    constexpr int NPASS = NT >= 4 ? 2 : 1;  // row passes per mat-vec
+    constexpr int NPASS = (NT % 4 == 0) ? 2 : 1;  // row passes per mat-vec (NT = 6, DP = 96: one pass of six row tiles)
     constexpr int NTP = NT / NPASS;         // row tiles per pass (even)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -1055,7 +1055,7 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
-        constexpr bool CARRYK = (NT_ == 8 || NT_ == 4) && M_ == 0;   /* carried / fused forms exist */ \
+        constexpr bool CARRYK = (NT_ == 8 || NT_ == 6 || NT_ == 4) && M_ == 0;   /* carried / fused forms exist */ \
         constexpr int NTC = CARRYK ? NT_ : 8;                                                     \
         constexpr bool HEAD = (NT_ == 8) && F_;   /* the C2 shape: draw specialised at compile time */ \
         if (dyn && M_ == 0) {                                                                     \
@@ -1109,7 +1109,7 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         if (full) CASE3F(NT_, true)   \
         else CASE3F(NT_, false)       \
     }
-        CASE3(2) CASE3(4) CASE3(8)
+        CASE3(2) CASE3(4) CASE3(6) CASE3(8)
 #undef CASE3
 #undef CASE3F
 #undef LAUNCH3
@@ -1131,7 +1131,7 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
             else LAUNCH(NT_, PBBI_STORMER_VERLET, false)          \
         }                                                         \
     }
-    CASE(2) CASE(4) CASE(8)
+    CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
 #undef LAUNCH
     PBBI_HIP(hipGetLastError());
@@ -1166,7 +1166,7 @@ int dense_build_fragments(pbbi_potential* pot, const double* P, const double* me
     pot->d_frag = nullptr;
     pot->d_mean_pad = nullptr;
     if (D > 128 || pot->dtype != PBBI_F64) return PBBI_OK;  // path unavailable; callers check
-    const int DP = D <= 32 ? 32 : (D <= 64 ? 64 : 128);
+    const int DP = D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 96 ? 96 : 128));
     const int NT = DP / 16, KS = DP / 4;
     std::vector<double> frag((size_t)DP * DP, 0.0), mu((size_t)DP, 0.0);
     for (int s = 0; s < KS; ++s)
@@ -1256,7 +1256,7 @@ int dense_fused_iterations(const IterArgs& a) {
 // each -- addressable with 32-bit offsets.
 bool dense_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
-    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && (a.pot->DP == 128 || a.pot->DP == 64) &&
+    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && (a.pot->DP == 128 || a.pot->DP == 96 || a.pot->DP == 64) &&
            a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) &&
            getenv("PBBI_DENSE_V1") == nullptr;
 }
@@ -1302,7 +1302,7 @@ static int dense_eval_launch(const EvalArgs& a, int mode) {
         if (full) LAUNCH(NT_, true)        \
         else LAUNCH(NT_, false)            \
     }
-    CASE(2) CASE(4) CASE(8)
+    CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
 #undef LAUNCH
     PBBI_HIP(hipGetLastError());

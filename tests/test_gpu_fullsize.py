@@ -216,7 +216,8 @@ def _stress_problem(D, zero_mean):
 @pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
 @pytest.mark.parametrize("compat", [True, False])
 @pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
-                                              (100, False, False), (64, False, False), (24, True, True)])
+                                              (100, False, False), (64, False, False), (24, True, True),
+                                              (96, True, False), (72, False, True)])
 def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, method):
     from test_gpu_parity import gpu_hmc_iter
     N, h, L = 333, 0.5, 4  # ragged: 333 = 2*128 + 77
@@ -248,7 +249,8 @@ def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, 
 @pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
 @pytest.mark.parametrize("compat", [True, False])
 @pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
-                                              (100, False, False)])
+                                              (100, False, False), (96, False, False), (80, True, True),
+                                              (64, True, False)])
 def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat, method):
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
@@ -292,7 +294,8 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
                                                      (100, False, True, False), (65, True, True, True),
                                                      (100, True, False, True), (64, True, False, True),
                                                      (64, False, True, False), (48, True, True, True),
-                                                     (33, False, False, False)])
+                                                     (33, False, False, False), (96, True, False, True),
+                                                     (80, False, True, False), (70, True, True, True)])
 def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
     """pbbi_hmc_run on the dense kernel at 32 < D <= 128 (round 3: padded D and D <= 64 too, fused launches
     included -- rows d >= D are handled by bounded buffer descriptors, not guards) keeps the gradient of the chain's position between

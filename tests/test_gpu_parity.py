@@ -198,7 +198,7 @@ def test_leapfrog_rosenbrock_vs_golden(P):
 
 
 @pytest.mark.parametrize("method", ["Leapfrog", "Stormer-Verlet"])
-@pytest.mark.parametrize("D", [8, 32, 100, 128])
+@pytest.mark.parametrize("D", [8, 32, 72, 96, 100, 128])
 def test_dense_integrate_vs_oracle(P, D, method):
     rs = np.random.RandomState(D)
     A = rs.standard_normal((D, D))
@@ -1855,7 +1855,7 @@ def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
         assert not to_numpy(rj).astype(bool)[still].any()
 
 
-@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True)])
+@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True), ("dense80", True)])
 @pytest.mark.parametrize("mode", ["uturn", "both"])
 def test_uturn_stop_dense_kernel(P, lib, case, mass, mode):
     """PBBI_UTURN_STOP on the dense MFMA kernel: a chain stops at the first step where (q - q_0) . v < 0 (the
@@ -2322,6 +2322,8 @@ F64_RUNS = [
     ("dense128_fused", "dense", 128, 300, 0, "float64", 1e-11, False),
     ("dense128_mass", "dense", 128, 150, 0, "float64", 1e-11, True),
     ("dense100", "dense", 100, 150, 0, "float64", 1e-11, False),
+    ("dense96", "dense", 96, 150, 0, "float64", 1e-11, False),
+    ("dense80_mass", "dense", 80, 150, 0, "float64", 1e-11, True),
     ("dense24", "dense", 24, 70, 0, "float64", 1e-11, True),
     ("gemm_dense200", "dense", 200, 150, 0, "float64", 1e-10, False),
     ("gemm_dense256_f32", "dense", 256, 128, 0, "float32", 2e-4, False),

@@ -2,7 +2,7 @@
 # dense-precision Gaussians across D: bench.py --workload dense lines into gpurun_out/<tag>/dense_d*.json
 tag=${1:-dense}
 mkdir -p gpurun_out/$tag
-for d in 32 64 100 128 256 512; do
+for d in 32 64 80 96 100 128 256 512; do
   n=65536
   python bench.py --workload dense --dim $d --chains $n --steps 50 --warmup 50 > gpurun_out/$tag/dense_d$d.json 2> gpurun_out/$tag/dense_d$d.err
   python - <<PY
