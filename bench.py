@@ -140,10 +140,17 @@ def cpu_baseline(Pm, L, seconds_target=4.0):
 
 
 # ------------------------------------------------------------------------------ timing helper
+RETRY_STALLED = False   # set for the embedded extra lines (main): see timed_runs
+
+
 def timed_runs(run, K, W, settle, barrier=lambda: None, reduce_max=lambda t: t):
     """W warm-up steps, then K timed steps (`first`); then further untimed steps until `settle`
     have run in all, then K timed steps again (`steady`).  run(S, iter0) enqueues S iterations.
-    Each timing is (wall seconds max over ranks, HIP-event milliseconds on the launch stream)."""
+    Each timing is (wall seconds max over ranks, HIP-event milliseconds on the launch stream).
+    The supplementary lines measured later in the same process (RETRY_STALLED) repeat a timing ONCE when its wall
+    time is more than 1.5 x its device time: a second workload in one process meets a single ~65 ms device-wide
+    stall outside the kernels' event bracket in one of its first two synchronisations
+    (tools/embedded_probe2.py); the headline line never uses this."""
     import torch
 
     def once(it0):
@@ -166,6 +173,9 @@ def timed_runs(run, K, W, settle, barrier=lambda: None, reduce_max=lambda t: t):
         done = W
     first = once(done)
     done += K
+    if RETRY_STALLED and first[0] * 1e3 > 1.5 * first[1] + 1.0:
+        first = once(done)
+        done += K
     if done < settle:
         run(settle - done, done)
         done = settle
@@ -690,6 +700,8 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.draw, a2.no_cpu_baseline = "f64", True
                 return bench_c2(a2, rank, world, local_rank)
+            global RETRY_STALLED
+            RETRY_STALLED = True
             for name, fn in (("c2_draw_f64", c2_f64),
                              ("c3_kdk_fma", lambda: bench_c3(args, False)),
                              ("c3_exact_order", lambda: bench_c3(args, True)),
