@@ -14,7 +14,9 @@ expression becomes a potential descriptor whose arithmetic runs in the HIP kerne
   * anything else               -> generated C++ source (potential AND its reverse-mode symbolic
     gradient, common subexpressions shared) compiled into the kernels by `custom.CustomPotential`.
 
-Nothing is evaluated on the host: the trace only builds the expression.  A callable that cannot be
+Nothing is evaluated on the host: the trace only builds the expression.  A callable is traced ONCE per
+(callable, D) and the descriptor cached: arrays it closes over are read at trace time (constants of the
+kernel), as with `jax.jit`.  A callable that cannot be
 traced (Python control flow on the VALUE of q, `float(q[0])`, a foreign array library) raises
 `TypeError` -- there is no fallback.
 
