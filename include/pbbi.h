@@ -260,7 +260,9 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
  * oracle) and by the dense MFMA kernel (D <= 128, both flags: the 16-chain tile keeps stepping while
  * one of its chains is live; the U-turn quantity is formed from the kernel's kick-drift-kick values, so a
  * chain whose (q - q_0) . v passes zero within rounding may stop one step apart from a reference-order
- * run); other paths return PBBI_ERR_UNSUPPORTED. */
+ * run); with PBBI_PER_CHAIN_STEPS alone (no U-turn stop) and PBBI_KDK_FMA also by the multi-lane kernels --
+ * harmonic / diagonal Gaussian 32 < D <= 256, Rosenbrock 32 < D <= 128, kick-drift-kick form, ~1e-13 from the
+ * reference order like every PBBI_KDK_FMA path; other paths return PBBI_ERR_UNSUPPORTED. */
 int pbbi_hmc_iter_dyn(const pbbi_potential* pot, int method, const void* q_in, const void* p_in,
                       const void* u_in, const void* mass, const int32_t* steps_in, void* q_out, void* p_out,
                       void* ratio_out, uint8_t* reject_out, int32_t* steps_out, int64_t N, int64_t ldn,

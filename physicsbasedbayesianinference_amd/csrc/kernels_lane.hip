@@ -709,6 +709,12 @@ inline bool streams(const pbbi_potential* pot) { return pot->dtype != PBBI_F64 |
 }  // namespace
 
 int lane_hmc_iter(const IterArgs& a) {
+    // per-chain step counts WITHOUT the U-turn stop, kick-drift-kick form, D > 32: the multi-lane kernels freeze
+    // finished chains by per-lane coefficients (k_sep_hmc / k_rosg_hmc <..., DYN>)
+    if (pbbi_dyn(a) && !(a.flags & PBBI_UTURN_STOP) && a.method == PBBI_LEAPFROG && a.pot->D > 32) {
+        if (sepn_applies(a)) return sepn_hmc_iter(a);
+        if (rosg_applies(a)) return rosg_hmc_iter(a);
+    }
     if (pbbi_dyn(a)) {  // per-chain trajectory lengths: the two-lane Rosenbrock kernel or k_lane_dyn_hmc
         static const bool no_lane2_dyn = (getenv("PBBI_NO_LANE2") != nullptr);
         if (!no_lane2_dyn && lane2_applies(a) && !streams(a.pot) && a.N > 0 &&
@@ -730,6 +736,10 @@ int lane_hmc_iter(const IterArgs& a) {
 }
 // which kernel family lane_hmc_iter hands these arguments to (pbbi_describe_run)
 const char* lane_route_name(const IterArgs& a) {
+    if (pbbi_dyn(a) && !(a.flags & PBBI_UTURN_STOP) && a.method == PBBI_LEAPFROG && a.pot->D > 32) {
+        if (sepn_applies(a)) return "k_sep_hmc<DYN>: separable potential, parts in waves, kick-drift-kick, per-chain step counts";
+        if (rosg_applies(a)) return "k_rosg_hmc<DYN>: Rosenbrock, 4 / 8 lanes per chain, kick-drift-kick, per-chain step counts";
+    }
     if (pbbi_dyn(a)) {
         if (getenv("PBBI_NO_LANE2") == nullptr && lane2_applies(a) && !streams(a.pot))
             return "k_ros2_hmc<DYN>: two lanes per chain, per-chain trajectory lengths";

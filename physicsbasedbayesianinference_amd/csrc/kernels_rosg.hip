@@ -36,6 +36,9 @@ struct RosgPrm {
     int L, D, flags, rng;
     uint64_t seed, iter, chain0;
     double cst;
+    // PBBI_PER_CHAIN_STEPS (k_rosg_hmc<..., DYN>): the chains' own step counts, uploaded or drawn (include/pbbi.h)
+    const int32_t* steps_in;
+    int32_t* steps_out;
 };
 
 template <int G>
@@ -59,8 +62,12 @@ struct RosgRun {
 // run.S > 1: the wave keeps its chains in registers for run.S consecutive iterations, and the potential
 // energy of the position an iteration starts from is the one the previous iteration formed (carried in a
 // register, the same value), as in k_ros2_hmc.
-template <int G, bool UNIT, bool FULL, int METHOD>
+// DYN (PBBI_PER_CHAIN_STEPS, Leapfrog): chain c takes its own L_c <= L steps; every lane keeps executing (the
+// kick's shuffles need the whole wave), a finished chain is frozen by per-lane coefficients -- drift step 0,
+// kick 0 -- its last kick is its own half kick, the wave stops with its longest chain.
+template <int G, bool UNIT, bool FULL, int METHOD, bool DYN = false>
 __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm, RosgRun run) {
+    static_assert(!DYN || METHOD == PBBI_LEAPFROG, "per-chain lengths: Leapfrog");
     constexpr int CPW = 64 / G;  // chains per wave
     const int lane = threadIdx.x;
     const int part = lane / CPW, c = lane % CPW;
@@ -174,7 +181,20 @@ __global__ void __launch_bounds__(64, 3) k_rosg_hmc(RosgPrm prm, RosgRun run) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    if constexpr (METHOD == PBBI_LEAPFROG) {
+    if constexpr (DYN) {
+        int Ln = prm.rng ? rng_steps(prm.seed, iter_k, chain, prm.L) : (prm.steps_in ? prm.steps_in[n0 + cc] : prm.L);
+        Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
+        kick(Ln > 0 ? hhm : 0.0);
+        for (int s = 0; s < prm.L; ++s) {
+            const bool act = s < Ln;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;  // wave-uniform
+            const double hq = act ? h : 0.0;
+#pragma unroll
+            for (int j = 0; j < DL; ++j) q[j] = fma(v[j], hq, q[j]);
+            kick(act ? (s + 1 == Ln ? hhm : hm) : 0.0);
+        }
+        if (valid && part == 0 && prm.steps_out) prm.steps_out[(int64_t)kf * prm.N + n0 + c] = Ln;
+    } else if constexpr (METHOD == PBBI_LEAPFROG) {
         if (prm.L > 0) {
             kick(hhm);
             for (int s = 0; s < prm.L; ++s) {
@@ -423,7 +443,15 @@ void launch(const IterArgs& a, const RosgPrm& prm, bool full) {
         if (full) hipLaunchKernelGGL((k_rosg_hmc<G, U_, true, M_>), grid, block, 0, a.stream, prm, run);  \
         else hipLaunchKernelGGL((k_rosg_hmc<G, U_, false, M_>), grid, block, 0, a.stream, prm, run);      \
     }
-    if (a.method == PBBI_LEAPFROG) {
+    if (pbbi_dyn(a)) {   // (lane_hmc_iter sends PBBI_PER_CHAIN_STEPS without PBBI_UTURN_STOP only)
+        if (a.mass) {
+            if (full) hipLaunchKernelGGL((k_rosg_hmc<G, false, true, PBBI_LEAPFROG, true>), grid, block, 0, a.stream, prm, run);
+            else hipLaunchKernelGGL((k_rosg_hmc<G, false, false, PBBI_LEAPFROG, true>), grid, block, 0, a.stream, prm, run);
+        } else {
+            if (full) hipLaunchKernelGGL((k_rosg_hmc<G, true, true, PBBI_LEAPFROG, true>), grid, block, 0, a.stream, prm, run);
+            else hipLaunchKernelGGL((k_rosg_hmc<G, true, false, PBBI_LEAPFROG, true>), grid, block, 0, a.stream, prm, run);
+        }
+    } else if (a.method == PBBI_LEAPFROG) {
         if (a.mass) ROSG_LAUNCH(false, PBBI_LEAPFROG) else ROSG_LAUNCH(true, PBBI_LEAPFROG)
     } else {
         if (a.mass) ROSG_LAUNCH(false, PBBI_STORMER_VERLET) else ROSG_LAUNCH(true, PBBI_STORMER_VERLET)
@@ -454,7 +482,7 @@ int rosg_hmc_iter(const IterArgs& a) {
                 (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
                 a.reject_out, a.N, a.ldn_in, a.ldn_out, a.h, pot->a, pot->b, inv_s, a.kT,
                 (-4.0 * pot->b) * inv_s, 2.0 * inv_s, (2.0 * pot->b) * inv_s, a.L, pot->D, a.flags,
-                a.rng, a.seed, a.iter, a.chain0, pot->cst};
+                a.rng, a.seed, a.iter, a.chain0, pot->cst, a.steps_in, a.steps_out};
     if (pot->D <= 32) launch<2>(a, prm, pot->D == 32);
     else if (pot->D <= 64) launch<4>(a, prm, pot->D == 64);
     else launch<8>(a, prm, pot->D == 128);

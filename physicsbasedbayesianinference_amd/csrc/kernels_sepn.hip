@@ -44,6 +44,9 @@ struct SepPrm {
     int L, D, flags, rng;
     uint64_t seed, iter, chain0;
     int harmonic;  // k_sep_exact_hmc: U = 0.5 sum k q^2 in the harmonic potential's own operation order
+    // PBBI_PER_CHAIN_STEPS (k_sep_hmc<..., DYN>): the chains' own step counts, uploaded or drawn (include/pbbi.h)
+    const int32_t* steps_in;
+    int32_t* steps_out;
 };
 
 // Where the iterations of a fused run put their results (pbbi_hmc_run, IterArgs::fuse_*; as Ros2Run in
@@ -63,8 +66,13 @@ struct SepRun {
 // kernel is bound by HBM, and a chain that is not re-read every iteration moves 3 instead of 4 slabs.
 // Every iteration ends with the position it stored (x + mu, or the old position of a rejected chain) and
 // starts the next one from that value minus mu, exactly what a launch of its own would load and form.
-template <bool UNIT, bool FULL, int METHOD>
+// DYN (PBBI_PER_CHAIN_STEPS, Leapfrog): chain c takes its own L_c <= L steps.  No lane leaves the loop -- a
+// finished chain is frozen by per-lane coefficients (drift step 0, kick 0), its last kick is its own half kick
+// -- and the wave stops when its longest chain has; every wave of the workgroup holds the same 64 chains, so
+// they all run the same count.
+template <bool UNIT, bool FULL, int METHOD, bool DYN = false>
 __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm, SepRun run) {
+    static_assert(!DYN || METHOD == PBBI_LEAPFROG, "per-chain lengths: Leapfrog");
     __shared__ double dH[2][MAXG][64];  // by iteration parity: one barrier per iteration is enough
     const int c = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
@@ -151,7 +159,24 @@ __global__ void __launch_bounds__(64 * MAXG) k_sep_hmc(SepPrm prm, SepRun run) {
 #pragma unroll
         for (int j = 0; j < DL; ++j) v[j] = v[j] / m;
     }
-    if constexpr (METHOD == PBBI_LEAPFROG) {
+    if constexpr (DYN) {
+        int Ln = prm.rng ? rng_steps(prm.seed, iter_k, chain, prm.L) : (prm.steps_in ? prm.steps_in[n0 + cc] : prm.L);
+        Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
+        const double c0 = Ln > 0 ? nhh : 0.0;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) v[j] = fma(pr[j] * q[j], c0, v[j]);
+        for (int s = 0; s < prm.L; ++s) {
+            const bool act = s < Ln;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;  // wave-uniform
+            const double hq = act ? h : 0.0, ck = act ? (s + 1 == Ln ? nhh : nhm) : 0.0;
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                q[j] = fma(v[j], hq, q[j]);
+                v[j] = fma(pr[j] * q[j], ck, v[j]);
+            }
+        }
+        if (valid && part == 0 && prm.steps_out) prm.steps_out[(int64_t)kf * prm.N + n0 + c] = Ln;
+    } else if constexpr (METHOD == PBBI_LEAPFROG) {
         if (prm.L > 0) {
 #pragma unroll
             for (int j = 0; j < DL; ++j) v[j] = fma(pr[j] * q[j], nhh, v[j]);
@@ -426,15 +451,18 @@ int sepn_hmc_iter(const IterArgs& a) {
                (const double*)a.mass, (double*)a.q_out, (double*)a.p_out, (double*)a.ratio_out,
                a.reject_out, (const double*)pot->d_mean, (const double*)pot->d_prec, a.N, a.ldn_in,
                a.ldn_out, a.h, pot->cst, a.kT, a.L, pot->D, a.flags, a.rng, a.seed, a.iter, a.chain0,
-               pot->kind == KIND_HARMONIC ? 1 : 0};
+               pot->kind == KIND_HARMONIC ? 1 : 0, a.steps_in, a.steps_out};
     const int G = (pot->D + DL - 1) / DL;
     const dim3 grid((unsigned)((a.N + 63) / 64)), block(64 * G);
     const bool full = (pot->D % DL == 0);
+    const bool dyn = pbbi_dyn(a);   // (lane_hmc_iter sends PBBI_PER_CHAIN_STEPS without PBBI_UTURN_STOP only)
     SepRun run{1, 0, 0, (int64_t)pot->D * a.N, (double*)a.q_out};
     if (a.fuse_S > 1) run = SepRun{a.fuse_S, a.fuse_wrap2, a.fuse_slab0, (int64_t)pot->D * a.N, (double*)a.fuse_q_base};
 #define SEP_LAUNCH(U_, F_)                                                                              \
     {                                                                                                   \
-        if (a.method == PBBI_LEAPFROG)                                                                  \
+        if (dyn)                                                                                        \
+            hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_LEAPFROG, true>), grid, block, 0, a.stream, prm, run); \
+        else if (a.method == PBBI_LEAPFROG)                                                             \
             hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_LEAPFROG>), grid, block, 0, a.stream, prm, run); \
         else                                                                                            \
             hipLaunchKernelGGL((k_sep_hmc<U_, F_, PBBI_STORMER_VERLET>), grid, block, 0, a.stream, prm, run);\

@@ -2810,3 +2810,58 @@ def test_two_ranks_on_one_gpu_sharded_kernels_and_overlapped_collection(tmp_path
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("kind,D,mass", [("diag", 64, False), ("diag", 200, True), ("diag", 40, True),
+                                         ("ros", 64, True), ("ros", 128, False), ("ros", 100, False)])
+@pytest.mark.parametrize("rng", ["upload", "philox"])
+def test_per_chain_steps_multilane_kdk_kernels(P, lib, kind, D, mass, rng):
+    """PBBI_PER_CHAIN_STEPS in the multi-lane kick-drift-kick kernels (round 3: k_sep_hmc / k_rosg_hmc <DYN>, D > 32;
+    finished chains frozen by per-lane coefficients): step counts and decisions equal to the oracle's
+    leapfrog_chain_dyn, states within the kick-drift-kick tolerance; 0 steps leaves a chain where it was."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    rs = np.random.RandomState(D)
+    if kind == "diag":
+        mu, prec = rs.standard_normal(D), rs.uniform(0.5, 2.0, D)
+        pot, op, h = P.GaussianDiag(mu, prec=prec, const=0.0), orc.pot_gauss_diag(mu, prec), 0.15
+        q0 = rs.standard_normal((D, 333))
+    else:
+        pot, op, h = P.Rosenbrock(D), orc.pot_rosenbrock(D), 0.02
+        q0 = 1.0 + 0.2 * rs.standard_normal((D, 333))
+    N, L, seed = 333, 9, 21
+    m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
+    md = as_device(m, 0, np.float64) if mass else None
+    flags = lib.COMPAT_P_FROM_OLDQ | lib.PER_CHAIN_STEPS | lib.KDK_FMA
+    qd = as_device(q0, 0, np.float64)
+    qo, po = empty((D, N), np.float64, 0), empty((D, N), np.float64, 0)
+    ro, rj, so = empty((N,), np.float64, 0), empty((N,), np.uint8, 0), empty((N,), np.int32, 0)
+    if rng == "upload":
+        p0 = rs.standard_normal((D, N)) * (np.sqrt(m) if mass else 1.0)
+        u = rs.uniform(size=N)
+        steps_in = rs.randint(0, L + 1, size=N).astype(np.int32)
+        steps_in[:70] = 0                                          # a whole wave of chains that do not move
+        pd, ud, sd = as_device(p0, 0, np.float64), as_device(u, 0, np.float64), torch.tensor(steps_in, device="cuda")
+        lib.call("pbbi_hmc_iter_dyn", pot.handle, 0, qd.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+                 md.data_ptr() if mass else None, sd.data_ptr(), qo.data_ptr(), po.data_ptr(), ro.data_ptr(),
+                 rj.data_ptr(), so.data_ptr(), N, N, h, L, flags, 1.0, stream_ptr(0))
+    else:
+        p0 = device_normal(lib, seed, lib.STREAM_MOMENTUM, 0, 0, D, N, 1.0, np.sqrt(m) if mass else None)
+        u = device_uniform(lib, seed, 0, 0, N)
+        steps_in = orc.philox_steps(seed, 0, 0, N, L)
+        lib.call("pbbi_hmc_run_dyn", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, qo.data_ptr(),
+                 po.data_ptr(), rj.data_ptr(), ro.data_ptr(), so.data_ptr(), N, N, h, L, 1, flags, seed, 0, 0, 1.0,
+                 stream_ptr(0))
+    torch.cuda.synchronize()
+    q_or, p_or = np.ascontiguousarray(q0), np.ascontiguousarray(p0)
+    r_or, rej_or, st_or = orc.hmc_iter_dyn(op, q_or, p_or, u, m, h, L, steps_in=steps_in)
+    assert np.array_equal(to_numpy(so), st_or)
+    assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
+    assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
+    if rng == "upload":
+        assert np.array_equal(to_numpy(qo)[:, :70], q0[:, :70])
+    # the U-turn stop stays with the kernels that can form the dot product
+    bad = lib.load().pbbi_hmc_iter_dyn(pot.handle, 0, qd.data_ptr(), qd.data_ptr(), ro.data_ptr(), None, None,
+                                       qo.data_ptr(), None, None, None, None, N, N, h, L,
+                                       flags | lib.UTURN_STOP, 1.0, None)
+    assert bad == -2   # PBBI_ERR_UNSUPPORTED
