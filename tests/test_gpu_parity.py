@@ -2858,8 +2858,9 @@ def test_per_chain_steps_multilane_kdk_kernels(P, lib, kind, D, mass, rng):
     assert np.array_equal(to_numpy(so), st_or)
     assert np.array_equal(to_numpy(rj).astype(bool), rej_or)
     assert scaled_err(to_numpy(qo), q_or) <= 1e-12 and scaled_err(to_numpy(po), p_or) <= 1e-12
-    if rng == "upload":
-        assert np.array_equal(to_numpy(qo)[:, :70], q0[:, :70])
+    if rng == "upload":   # (the separable kernel stores (q - mu) + mu: the start up to one rounding)
+        assert np.max(np.abs(to_numpy(qo)[:, :70] - q0[:, :70])) <= 2e-15
+        assert not to_numpy(rj).astype(bool)[:70].any()
     # the U-turn stop stays with the kernels that can form the dot product
     bad = lib.load().pbbi_hmc_iter_dyn(pot.handle, 0, qd.data_ptr(), qd.data_ptr(), ro.data_ptr(), None, None,
                                        qo.data_ptr(), None, None, None, None, N, N, h, L,
