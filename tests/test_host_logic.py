@@ -260,7 +260,7 @@ def test_custom_potential_plugin_builds_and_exports():
     for src, dtype, D in ((QUARTIC, "float64", 11), (QUARTIC, "float64", 40), (LOGISTIC, "float64", 5),
                           (QUARTIC, "float32", 7), (COIN_TOSS_SOURCE, "float64", 1),
                           (QUARTIC, "float64", 9), (QUARTIC, "float64", 20), (QUARTIC, "float64", 24),
-                          (QUARTIC, "float64", 12), (COIN_TOSS_SOURCE, "float64", 2),
+                          (QUARTIC, "float64", 12), (COIN_TOSS_SOURCE, "float64", 2), (QUARTIC, "float64", 48),
                           # sources without a gradient: dual-number autodiff (csrc/pbbi_autodiff.h)
                           (QUARTIC_AD, "float64", 11), (QUARTIC_AD, "float64", 40), (LOGISTIC_AD, "float64", 5),
                           (COIN_TOSS_AD, "float64", 2), (QUARTIC_AD, "float32", 7),

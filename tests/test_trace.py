@@ -206,3 +206,33 @@ def test_eight_schools_potential_traces_and_differentiates():
         ref_U = np.array([fn(q[:, n]) for n in range(q.shape[1])])
         assert np.allclose(U, ref_U, rtol=1e-13)
         assert np.allclose(g, central_diff(fn, q), rtol=2e-6, atol=2e-6)
+
+
+def test_generated_sources_build_for_gfx950():
+    """The generated sources of the traced GPU tests compile into plugin kernels for gfx950 here, without a GPU
+    (hipcc cross-compiles) -- and the built plugins travel to the GPU box in the in-tree cache, so that the -m gpu
+    run does not spend its time in hipcc.  Same callables as tests/test_gpu_parity.py::test_traced_* /
+    test_tempering_* / test_eight_schools_*."""
+    from conftest import load_golden
+    from physicsbasedbayesianinference_amd.custom import compile_plugin
+    from physicsbasedbayesianinference_amd.models import eight_schools_potential
+    cases = []
+    k = load_golden("G1_leapfrog_harmonic")["springConsts"]
+    cases.append((2, lambda q: 0.5 * jnp.dot(np.asarray(k, dtype=np.float64), q ** 2)))
+    for name in ("G4_getsamples_dense_d8", "G11_getsamples_test2", "G4b_getsamples_dense_mean_d16"):
+        g = load_golden(name)
+        mean, Pm, const = g["mean"], g["precision"], float(g["const"])
+        cases.append((int(g["D"]), (lambda mean, Pm, const: lambda q: 0.5 * jnp.dot(q - mean, jnp.dot(Pm, q - mean)) + const)(mean, Pm, const)))
+    rs = np.random.RandomState(4)
+    X = rs.standard_normal((24, 5))
+    y = (rs.uniform(size=24) < 0.5).astype(np.float64)
+    cases.append((5, lambda w: jnp.sum(softplus(X @ w) - y * (X @ w)) + 0.5 * jnp.dot(w, w)))
+    a, b, sig, wa = np.array([-4.0, 0.0]), np.array([4.0, 0.0]), 0.6, 0.7
+    cases.append((2, lambda q: -jnp.logaddexp(np.log(wa) - 0.5 * jnp.sum((q - a) ** 2) / sig ** 2,
+                                              np.log(1.0 - wa) - 0.5 * jnp.sum((q - b) ** 2) / sig ** 2)))
+    cases.append((10, eight_schools_potential(centered=False)))
+    cases.append((10, eight_schools_potential(centered=True)))
+    for D, fn in cases:
+        plan = jnp.plan_potential(fn, D=D, prefer="source")
+        so = compile_plugin(plan["source"], "float64", D=D)
+        assert os.path.exists(so)
