@@ -1055,8 +1055,8 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
-        constexpr bool CARRYK = (NT_ == 8 || NT_ == 6 || NT_ == 4) && M_ == 0;   /* carried / fused forms exist */ \
-        constexpr int NTC = CARRYK ? NT_ : 8;                                                     \
+        constexpr bool CARRYK = M_ == 0;   /* carried / fused forms exist */ \
+        constexpr int NTC = NT_;                                                                  \
         constexpr bool HEAD = (NT_ == 8) && F_;   /* the C2 shape: draw specialised at compile time */ \
         if (dyn && M_ == 0) {                                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, 0, Z_, PBBI_LEAPFROG, true>, lds)) return rc; \
@@ -1252,11 +1252,11 @@ int dense_fused_iterations(const IterArgs& a) {
 }
 
 // May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Plain
-// Leapfrog on the two-wave kernel at 32 < D <= 128 (padded D included: DP = 64 or 128), both slabs -- DP rows
+// Leapfrog on the two-wave kernel at D <= 128 (padded D included: DP = 32, 64, 96 or 128), both slabs -- DP rows
 // each -- addressable with 32-bit offsets.
 bool dense_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
-    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && (a.pot->DP == 128 || a.pot->DP == 96 || a.pot->DP == 64) &&
+    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP != 0 &&
            a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) &&
            getenv("PBBI_DENSE_V1") == nullptr;
 }

@@ -1060,7 +1060,6 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
             const uint64_t lim = (((uint64_t)1 << 31) - 1) / ((uint64_t)pot->DP * 16u);
             if (S < 2) d += "a run of one iteration";
             else if (method != PBBI_LEAPFROG || L < 1 || pbbi_dyn(a)) d += "plain Leapfrog runs with L >= 1 only";
-            else if (pot->DP != 128 && pot->DP != 96 && pot->DP != 64) d += "the carried form exists for 32 < D <= 128";
             else if ((uint64_t)N > lim)
                 d += "the two carried-gradient slabs (D*N*16 bytes) must stay below 2^31 for 32-bit buffer offsets: "
                      "at D = " + std::to_string(pot->D) + " (rows padded to " + std::to_string(pot->DP) + ") that is N <= " + std::to_string(lim) +
