@@ -295,9 +295,11 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
                                                      (100, True, False, True), (64, True, False, True),
                                                      (64, False, True, False), (48, True, True, True),
                                                      (33, False, False, False), (96, True, False, True),
-                                                     (80, False, True, False), (70, True, True, True)])
+                                                     (80, False, True, False), (70, True, True, True),
+                                                     (32, True, False, True), (24, False, True, False),
+                                                     (7, True, True, True)])
 def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
-    """pbbi_hmc_run on the dense kernel at 32 < D <= 128 (round 3: padded D and D <= 64 too, fused launches
+    """pbbi_hmc_run on the dense kernel at D <= 128 (round 3: padded D and every tile size DP = 32 / 64 / 96 / 128, fused launches
     included -- rows d >= D are handled by bounded buffer descriptors, not guards) keeps the gradient of the chain's position between
     iterations (kernels_dense.hip CARRY: accepted chains take g(q_new) of the previous launch, rejected
     ones the gradient they started from) instead of forming it again.  One run of S iterations must equal
