@@ -331,7 +331,7 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
     each = run(1)       # every iteration forms its own
     for a, b in zip(one, each):
         assert np.array_equal(a, b)
-    assert 0.1 < one[2].mean() < 0.8
+    assert 0.02 < one[2].mean() < 0.8   # (rejections happen: the selector both stays and flips)
     qd = as_device(q0, 0, np.float64)   # burn-in form: nothing recorded, same final state
     lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, None, None, None,
              None, N, N, h, L, S, flags, seed, iter0, chain0, 1.0, st)
