@@ -464,6 +464,82 @@ __global__ void __launch_bounds__(BLOCK) k_lane_dyn_hmc(DynPrm<T> dp, Pot pot) {
     if (dp.steps_out) dp.steps_out[n] = steps;
 }
 
+// One GIST (self-tuning no-U-turn) iteration of a chain, fused: forward U-turn search from (q, p), the length
+// draw, the proposal (L steps from the re-read q and the re-drawn p), the backward search from (q', -p'), the
+// accept test with tau_f / tau_b -- include/pbbi.h pbbi_hmc_run_gist, oracle_hmc_iter_gist; the same arithmetic as
+// the composed form (three k_lane_dyn_hmc launches + the small kernels of pbbi_api.hip), so the same bits.  The
+// proposal is parked in q_out / p_out before the backward search (q_out must not alias q_in); a rejected chain
+// overwrites it with its old position.  In-kernel draws only.  steps_out: (3, N) = tau_f, L, tau_b.
+template <typename T, typename Pot, int DMAX, bool FULL, bool UNIT>
+__global__ void __launch_bounds__(BLOCK) k_lane_gist_hmc(DynPrm<T> dp, Pot pot) {
+    const HmcPrm<T>& prm = dp.b;
+    const int64_t n0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t n = n0 + threadIdx.x;
+    if (n >= prm.N) return;
+    const int D = prm.D;
+    const T m = UNIT ? T(1) : prm.mass[n];
+    const uint64_t chain = prm.chain0 + (uint64_t)n;
+    const uint32_t voff = (uint32_t)threadIdx.x * (uint32_t)sizeof(T);
+    const uint32_t rin = (uint32_t)prm.ldn_in * (uint32_t)sizeof(T);
+    const uint32_t rout = (uint32_t)prm.ldn_out * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t bq = rows_rsrc<T, FULL>(prm.q_in, D, prm.ldn_in, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bqo = rows_rsrc<T, FULL>(prm.q_out, D, prm.ldn_out, prm.N, n0);
+    const __amdgpu_buffer_rsrc_t bpo = rows_rsrc<T, FULL>(prm.p_out, D, prm.ldn_out, prm.N, n0);
+    const double pstd = sqrt((double)m * prm.kT);  // src/ensemble.py:88
+    const bool f64 = (prm.flags & PBBI_DRAW_F64) != 0;
+    T q[DMAX], p[DMAX], v[DMAX];
+    auto load_q = [&]() {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) q[d] = load_row<T, FULL>(bq, voff, rin, d, D);
+    };
+    load_q();
+    draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd, f64);
+    const T oldH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+    const int tau_f = integrate_chain_dyn<T, Pot, DMAX, UNIT>(pot, q, p, v, m, prm.h, prm.L, true);
+    const PhiloxOut x = rng_block(prm.seed, /*PBBI_STREAM_STEPS*/ 3u, prm.iter, chain, 0xFFFFFFFFu);
+    int L = 1 + (int)(u53(x.x0, x.x1) * (double)tau_f);
+    L = L > tau_f ? tau_f : L;
+    load_q();
+    draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd, f64);
+    integrate_chain_dyn<T, Pot, DMAX, UNIT>(pot, q, p, v, m, prm.h, L, false);
+    const T newH = hamiltonian<T, Pot, DMAX>(pot, q, p, m);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
+    if (prm.p_out) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) p[d] = -p[d];
+    const int tau_b = integrate_chain_dyn<T, Pot, DMAX, UNIT>(pot, q, p, v, m, prm.h, prm.L, true);
+    const double hr = (double)exp((oldH - newH) * (T)pbbi_accept_beta(prm.flags, prm.kT));
+    const double ratio = (L <= tau_b) ? hr * ((double)tau_f / (double)tau_b) : 0.0;
+    const double u = rng_uniform(prm.seed, prm.iter, chain);
+    const bool reject = (ratio == ratio) && (u > (ratio < 1.0 ? ratio : 1.0));
+    if (reject) {
+        load_q();
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bqo, voff, rout, d, D, q[d]);
+        if (prm.p_out) {
+            if (prm.flags & PBBI_COMPAT_P_FROM_OLDQ) {
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) p[d] = q[d];
+            } else {
+                draw_momentum<T, DMAX>(p, D, prm.seed, prm.iter, chain, pstd, f64);
+            }
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) store_row<T, FULL>(bpo, voff, rout, d, D, p[d]);
+        }
+    }
+    if (prm.ratio_out) prm.ratio_out[n] = (T)ratio;
+    if (prm.reject_out) prm.reject_out[n] = reject ? 1 : 0;
+    if (dp.steps_out) {
+        dp.steps_out[n] = tau_f;
+        dp.steps_out[prm.N + n] = L;
+        dp.steps_out[2 * prm.N + n] = tau_b;
+    }
+}
+
 template <typename T>
 struct IntPrm {
     T* q;
@@ -784,6 +860,48 @@ int lane_dyn_hmc_iter(const IterArgs& a) {
                     } else {
                         auto f = make_sep<T, DM, FULL>(pot);
                         hipLaunchKernelGGL((k_lane_dyn_hmc<T, decltype(f), DM, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                                           a.stream, prm, f);
+                    }
+                });
+            });
+        }
+    });
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}
+
+// one fused GIST iteration (k_lane_gist_hmc): elementwise potentials, fp64, D <= 32, in-kernel draws; a.L = L_max,
+// a.steps_out = (3, N) tau_f / L / tau_b or nullptr.  false: the caller composes the iteration from the masked
+// kernels instead.
+bool lane_gist_applies(const pbbi_potential* pot) {
+    return pot->kind != KIND_GAUSS_DENSE && pot->kind != KIND_CUSTOM && pot->dtype == PBBI_F64 && pot->D <= 32 &&
+           getenv("PBBI_GIST_COMPOSED") == nullptr;
+}
+int lane_gist_iter(const IterArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (int rc = check_ld(pot, a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out)) return rc;
+    if (a.N == 0) return PBBI_OK;
+    if (a.q_in == a.q_out) return pbbi_fail(PBBI_ERR_INVALID, "GIST: q_out must not alias q_in");
+    typedef double T;
+    DynPrm<T> prm{{(const T*)a.q_in, nullptr, nullptr, (const T*)a.mass, (T*)a.q_out, (T*)a.p_out, (T*)a.ratio_out,
+                   a.reject_out, a.N, a.ldn_in, a.ldn_out, (T)a.h, a.L, pot->D, a.flags, 1, a.seed, a.iter, a.chain0,
+                   a.kT},
+                  nullptr, a.steps_out};
+    const dim3 grid = grid_for(a.N);
+    with_dmax(pot->D, [&](auto dm) {
+        constexpr int DM = decltype(dm)::value;
+        if constexpr (DM <= 32) {
+            with_bool(pot->D == DM, [&](auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                with_bool(a.mass == nullptr, [&](auto unit) {
+                    constexpr bool UNIT = decltype(unit)::value;
+                    if (pot->kind == KIND_ROSENBROCK) {
+                        auto f = make_ros<T, DM, FULL>(pot);
+                        hipLaunchKernelGGL((k_lane_gist_hmc<T, decltype(f), DM, FULL, UNIT>), grid, dim3(BLOCK), 0,
+                                           a.stream, prm, f);
+                    } else {
+                        auto f = make_sep<T, DM, FULL>(pot);
+                        hipLaunchKernelGGL((k_lane_gist_hmc<T, decltype(f), DM, FULL, UNIT>), grid, dim3(BLOCK), 0,
                                            a.stream, prm, f);
                     }
                 });

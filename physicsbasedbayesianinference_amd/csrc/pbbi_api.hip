@@ -8,6 +8,8 @@
 #include <new>
 #include <vector>
 
+#include <type_traits>
+
 #include "pbbi_internal.h"
 #include "pbbi_rng.h"
 
@@ -539,6 +541,31 @@ static int gist_run(const pbbi_potential* pot, void* q_state, const void* mass, 
                     hipStream_t st) {
     const int D = pot->D;
     const size_t slab = (size_t)D * (size_t)N;
+    if constexpr (std::is_same<T, double>::value) {
+        if (lane_gist_applies(pot)) {   // elementwise potential, D <= 32: ONE launch per iteration (k_lane_gist_hmc)
+            Scratch ws0(st);
+            double* q0 = (double*)ws0.get(slab * sizeof(double));
+            if (!q0) return pbbi_fail(PBBI_ERR_HIP, "hipMallocAsync failed for the GIST workspace");
+            PBBI_HIP(hipMemcpy2DAsync(q0, (size_t)N * 8, q_state, (size_t)ldn * 8, (size_t)N * 8, (size_t)D,
+                                      hipMemcpyDeviceToDevice, st));
+            for (int i = 0; i < S; ++i) {
+                IterArgs a{};
+                a.pot = pot; a.method = PBBI_LEAPFROG; a.mass = mass; a.N = N; a.h = h; a.L = Lmax; a.rng = 1;
+                a.kT = kT; a.stream = st; a.ldn_in = N; a.ldn_out = N; a.flags = flags;
+                a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0;
+                a.q_in = (i == 0) ? q0 : (double*)samples_out + (size_t)(i - 1) * slab;
+                a.q_out = (double*)samples_out + (size_t)i * slab;
+                a.p_out = momenta_out ? (double*)momenta_out + (size_t)i * slab : nullptr;
+                a.ratio_out = ratio_out ? (double*)ratio_out + (size_t)i * N : nullptr;
+                a.reject_out = reject_out ? reject_out + (size_t)i * N : nullptr;
+                a.steps_out = tau_out ? tau_out + (size_t)i * 3 * N : nullptr;
+                if (int rc = lane_gist_iter(a)) return rc;
+            }
+            PBBI_HIP(hipMemcpy2DAsync(q_state, (size_t)ldn * 8, (const double*)samples_out + (size_t)(S - 1) * slab,
+                                      (size_t)N * 8, (size_t)N * 8, (size_t)D, hipMemcpyDeviceToDevice, st));
+            return PBBI_OK;
+        }
+    }
     Scratch ws(st);
     T* p_draw = (T*)ws.get(slab * sizeof(T));
     T* scrQ = (T*)ws.get(slab * sizeof(T));

@@ -191,6 +191,9 @@ int lane_fused_iterations(const IterArgs& a);
 const char* lane_route_name(const IterArgs& a);  // the kernel family lane_hmc_iter picks (pbbi_describe_run)
 // per-chain trajectory lengths (k_lane_dyn_hmc: elementwise potentials, fp64, D <= 32, Leapfrog)
 int lane_dyn_hmc_iter(const IterArgs& a);
+// one GIST iteration fused into one launch (k_lane_gist_hmc; pbbi_hmc_run_gist): elementwise potentials, fp64, D <= 32
+bool lane_gist_applies(const pbbi_potential* pot);
+int lane_gist_iter(const IterArgs& a);
 // harmonic / diagonal Gaussian, 16 < D <= 256, PBBI_KDK_FMA: 16-dim parts in the waves of a workgroup, kernels_sepn.hip
 bool sepn_applies(const IterArgs& a);
 int sepn_hmc_iter(const IterArgs& a);

@@ -2866,3 +2866,31 @@ def test_per_chain_steps_multilane_kdk_kernels(P, lib, kind, D, mass, rng):
                                        qo.data_ptr(), None, None, None, None, N, N, h, L,
                                        flags | lib.UTURN_STOP, 1.0, None)
     assert bad == -2   # PBBI_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("case", ["diag8", "ros32", "harm3"])
+def test_gist_fused_lane_kernel_equals_the_composed_form(P, lib, case, monkeypatch):
+    """pbbi_hmc_run_gist serves elementwise potentials with D <= 32 by ONE launch per iteration (k_lane_gist_hmc:
+    forward search, length draw, proposal, backward search and accept test of a chain in its lane); every other
+    handle -- and these with PBBI_GIST_COMPOSED=1 -- by three masked launches plus the small kernels.  Same
+    arithmetic: the two forms agree bit for bit in every output."""
+    rs = np.random.RandomState(7)
+    if case == "diag8":
+        D, h = 8, 0.25
+        pot = P.GaussianDiag(rs.standard_normal(D), prec=rs.uniform(0.3, 3.0, D), const=0.0)
+    elif case == "harm3":
+        D, h = 3, 0.2
+        pot = P.Harmonic(np.array([0.5, 2.0, 9.0]))
+    else:
+        D, h = 32, 0.03
+        pot = P.Rosenbrock(D)
+    N, S, Lmax, seed = 700, 5, 50, 3
+    m = 1.0 + (np.arange(N) % 3) * 0.5
+    q0 = (1.0 if case == "ros32" else 0.0) + 0.5 * rs.standard_normal((D, N))
+    monkeypatch.delenv("PBBI_GIST_COMPOSED", raising=False)
+    fused = _gist_run(lib, pot, q0, m, h, Lmax, S, lib.COMPAT_P_FROM_OLDQ, seed, 1, 9)
+    monkeypatch.setenv("PBBI_GIST_COMPOSED", "1")
+    composed = _gist_run(lib, pot, q0, m, h, Lmax, S, lib.COMPAT_P_FROM_OLDQ, seed, 1, 9)
+    for a, b in zip(fused, composed):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert 0.0 < fused[2].mean() < 0.9
