@@ -372,7 +372,11 @@ def bench_gist(args):
     from physicsbasedbayesianinference_amd import _lib
     d, N, h = args.dim, args.chains, STEP
     K, W, Lmax = min(args.steps, 20), min(args.warmup, 5), 64
-    pot = P.GaussianDense(None, precision=precision_matrix(d), const=0.0)
+    if args.potential == "diag":   # elementwise potential, D <= 32: one fused launch per iteration (k_lane_gist_hmc)
+        rs = np.random.RandomState(0)
+        pot = P.GaussianDiag(rs.standard_normal(d), prec=rs.uniform(0.5, 2.0, d), const=0.0)
+    else:
+        pot = P.GaussianDense(None, precision=precision_matrix(d), const=0.0)
     stream = torch.cuda.current_stream().cuda_stream
     q = torch.empty((d, N), dtype=torch.float64, device="cuda")
     _lib.call("pbbi_philox_normal", 7, _lib.STREAM_POSITION, 0, 0, d, N, N, 1.0, None, _lib.F64, 0, q.data_ptr(), stream)
@@ -394,7 +398,11 @@ def bench_gist(args):
         "metric": f"leapfrog-steps*chains/sec; GIST (self-tuning no-U-turn) on a dense Gaussian d={d}, ensemble={N}",
         "value": K * steps * N / t, "value_steady": K * steps * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": t * 1e3 / K, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"GIST, dense precision d={d}, {N} chains, h={h}, L_max={Lmax}",
+        "config": {"workload": f"GIST, {'diagonal' if args.potential == 'diag' else 'dense precision'} Gaussian d={d}, {N} chains, "
+                               f"h={h}, L_max={Lmax}",
+                   "form": "composed (PBBI_GIST_COMPOSED)" if os.environ.get("PBBI_GIST_COMPOSED") else
+                           ("one fused launch per iteration" if args.potential == "diag" and d <= 32 else
+                            "three masked launches + small kernels per iteration"),
                    "mean_tau_forward": tf, "mean_length": Ld, "mean_tau_backward": tb,
                    "leapfrog_steps_per_chain_and_iteration": steps,
                    "accept_rate": 1.0 - float(reject.float().mean().item()),
