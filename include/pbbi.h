@@ -246,7 +246,7 @@ int pbbi_hmc_run(const pbbi_potential* pot, int method, void* q_state, const voi
 
 /* What pbbi_hmc_run would do with these arguments, in words, written to out (NUL-terminated, truncated to
  * out_len): the kernel family, whether the run carries the gradient between iterations and -- if not -- why
- * (e.g. the dense D = 128 path carries below N = 2^31 / (16 D) = 1 048 576 chains per call only: beyond, the
+ * (e.g. the dense D = 128 path carries below N = 2^32 / (16 D) = 2 097 152 chains per call only: beyond, the
  * two carried slabs pass the 32-bit buffer offsets), and how many iterations one launch covers.  Nothing is
  * launched. */
 int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t ldn, int L, int S, int flags,

@@ -1251,13 +1251,15 @@ int dense_fused_iterations(const IterArgs& a) {
     return chunk;
 }
 
+// (both slabs are addressed from ONE descriptor with unsigned 32-bit byte offsets: row offset + lane offset + slab
+//  select stay below 2^32 while the two slabs together do, with a margin for the lane term)
 // May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Plain
 // Leapfrog on the two-wave kernel at D <= 128 (padded D included: DP = 32, 64, 96 or 128), both slabs -- DP rows
 // each -- addressable with 32-bit offsets.
 bool dense_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
     return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP != 0 &&
-           a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < ((uint64_t)1 << 31) &&
+           a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < PBBI_CARRY_MAX_BYTES &&
            getenv("PBBI_DENSE_V1") == nullptr;
 }
 

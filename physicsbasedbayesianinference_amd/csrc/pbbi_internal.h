@@ -215,6 +215,7 @@ int stream_integrate(const IntegrateArgs& a);
 int stream_eval(const EvalArgs& a);
 int stream_energy(const EvalArgs& a);
 // dense-precision Gaussian, MFMA register-resident (D <= 128), kernels_dense.hip
+#define PBBI_CARRY_MAX_BYTES (((uint64_t)1 << 32) - ((uint64_t)1 << 20))  /* carried dense slabs: 2 * DP * N * 8 below this */
 int dense_hmc_iter(const IterArgs& a);
 bool dense_carry_applies(const IterArgs& a);  // may a run on these arguments carry the gradient?
 int dense_fused_iterations(const IterArgs& a);

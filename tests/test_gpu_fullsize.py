@@ -569,3 +569,26 @@ def test_chain_per_lane_run_fused_bit_identically(P, lib, kind, D, mass, method,
         assert np.array_equal(a, b)
     assert 0.02 < one[2].mean() < 0.98
     assert np.array_equal(run(S, record=False)[4], one[4])
+
+
+def test_dense_carried_run_beyond_two_to_the_31_bytes(P, lib):
+    """The carried-gradient slabs of the dense kernel are addressed with unsigned 32-bit byte offsets from one
+    descriptor.  Round 2 stopped carrying at D*N*16 >= 2^31 (N = 2^20 at D = 128); the offsets are good to 2^32
+    (pbbi_describe_run: N <= 2 096 639).  N = 2^20 + 37 puts the last chains' slab-1 offsets past 2^31: a fused,
+    carried run of 4 iterations there against the oracle, first / last / boundary chains."""
+    D, N, L, h, S, seed = 128, (1 << 20) + 37, 10, 0.1, 4, 42
+    Pm = c2_precision(D)
+    pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
+    import ctypes
+    buf = ctypes.create_string_buffer(512)
+    lib.call("pbbi_describe_run", pot.handle, 0, N, N, L, S, 1, buf, len(buf))
+    assert "carried between iterations: yes" in buf.value.decode()
+    samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, lib.COMPAT_P_FROM_OLDQ, seed, 1.0, 0.0)
+    worst = [0.0]
+
+    def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
+        assert np.array_equal(grej, rej), f"group {g} iteration {i}"
+        worst[0] = max(worst[0], scaled_err(gq, q), scaled_err(gp, p))
+    starts = [0, N - GROUP, (1 << 20) - 8, (1 << 19) + 3, N - 128 - 5]
+    replay_groups(lib, op, starts, samples, momenta, reject, qf, D, S, h, L, seed, 1.0, 0.0, True, np.float64, check)
+    assert worst[0] <= 1e-11, worst[0]

@@ -2460,9 +2460,9 @@ def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
     dense = P.GaussianDense(None, precision=Pm, const=0.0)
     d = describe(dense, 65536)
     assert "k_dense_hmc" in d and "carried between iterations: yes" in d and "up to 64" in d
-    d = describe(dense, 1 << 20)                      # one chain past the cliff
-    assert "carried between iterations: no" in d and "N <= 1048575 chains" in d and "shard" in d
-    assert "carried between iterations: yes" in describe(dense, (1 << 20) - 1)
+    d = describe(dense, 1 << 21)                      # past the cliff: 2 * D * N * 8 bytes would pass 2^32
+    assert "carried between iterations: no" in d and "N <= 2096639 chains" in d and "shard" in d
+    assert "carried between iterations: yes" in describe(dense, 2096639)
     assert "plain Leapfrog" in describe(dense, 1000, method=1)
     assert "32 < D <= 128" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
     assert "k_ros2_hmc" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.KDK_FMA)
