@@ -2464,7 +2464,8 @@ def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
     assert "carried between iterations: no" in d and "N <= 2096639 chains" in d and "shard" in d
     assert "carried between iterations: yes" in describe(dense, 2096639)
     assert "plain Leapfrog" in describe(dense, 1000, method=1)
-    assert "32 < D <= 128" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
+    assert "carried between iterations: yes" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
+    assert "a run of one iteration" in describe(dense, 1000, S=1)
     assert "k_ros2_hmc" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.KDK_FMA)
     assert "double precision" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.DRAW_F64)
     assert "k_sep_hmc" in describe(P.GaussianDiag(np.zeros(64), prec=np.ones(64), const=0.0), 4096, flags=1 | lib.KDK_FMA)
