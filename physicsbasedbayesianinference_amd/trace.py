@@ -881,7 +881,7 @@ def _gradient_nodes(root, D):
         op, a = n.op, n.args
 
         def push(node, val):
-            if node.op != "const":
+            if node.op not in ("const", "cparam"):
                 adj.setdefault(node.id, []).append(val)
         if op == "in":
             grads[n.val] = g
@@ -926,7 +926,7 @@ def _gradient_nodes(root, D):
             zero = tr.const(0.0)
             push(a[2], _select(c, g, zero))
             push(a[3], _select(c, zero, g))
-        elif op in ("sign", "const"):
+        elif op in ("sign", "const", "cparam"):
             pass
         elif op in ("gausslog", "gausspdf"):
             raise TraceError("multivariate_normal.pdf / logpdf may only appear as  -logpdf(q, ...)  or  "
@@ -957,6 +957,9 @@ def _emit(order, name_of, lines):
             continue
         if op == "in":
             name_of[n.id] = f"q[{n.val}]"
+            continue
+        if op == "cparam":   # a per-iteration constant of a rolled sum: declared at the top of its loop
+            name_of[n.id] = f"c{n.val}"
             continue
         name = f"t{n.id}"
         name_of[n.id] = name
@@ -1009,6 +1012,147 @@ def generate_source(root, grads):
     src += ["template <class Q, class G>", "PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {"]
     src += g_lines + [f"    g[{j}] = {names[g.id]};" for j, g in enumerate(grads)] + ["}"]
     return "\n".join(src) + "\n"
+
+
+# ------------------------------------------------------------------------------------ sums over data, rolled
+# A likelihood is a sum over observations of terms of ONE shape -- sum_i softplus(x_i . w) - y_i x_i . w --
+# and the trace unrolls it into M copies that differ in their constants only.  As straight-line code that is
+# thousands of statements inlined into every kernel of the plugin: hipcc needs minutes for M = 64 and does not
+# finish for M = 256.  So the terms of the top-level sum are grouped by SHAPE (the expression with its constants
+# blanked); a group with many members becomes a loop over a table of constants (the plugin's `prm` array, read
+# with wave-uniform addresses), whose body -- and the body's symbolic gradient -- is generated once.
+ROLL_MIN_TERMS = 8        # fewer terms of a shape stay unrolled
+ROLL_MIN_OPS = 400        # small traces stay straight-line code
+
+
+def _flatten_sum(root):
+    """root == sum of sign * term.  The top-level chain of binary add / sub / neg is opened; the arguments of an
+    n-ary sum (`sum(array)`, `dot`) met on the way ARE the terms -- they are not opened further, so that what the
+    callable wrote per observation stays one term of one shape."""
+    out, stack_ = [], [(root, 1.0)]
+    while stack_:
+        n, sg = stack_.pop()
+        if n.op == "addn":
+            out.extend((sg, a) for a in n.args)
+        elif n.op == "add":
+            for a in reversed(n.args):
+                stack_.append((a, sg))
+        elif n.op == "sub":
+            stack_.append((n.args[1], -sg))
+            stack_.append((n.args[0], sg))
+        elif n.op == "neg":
+            stack_.append((n.args[0], -sg))
+        else:
+            out.append((sg, n))
+    return out
+
+
+def _shape_of(node, seen, consts):
+    """Signature of one term's expression DAG with its constants blanked: a sub-expression met again is a
+    back-reference (it is ONE value in the loop body too), constants are collected at their first visit."""
+    idx = seen.get(node.id)
+    if idx is not None:
+        return ("ref", idx)
+    seen[node.id] = len(seen)
+    if node.op == "const":
+        consts.append(_cval(node))
+        return "C"
+    if node.op == "in":
+        return ("in", node.val)
+    return (node.op, node.val if node.op in ("powi", "select") else None,
+            tuple(_shape_of(a, seen, consts) for a in node.args))
+
+
+def _template_of(node, memo, counter):
+    """the term with its k-th constant (first-visit order of _shape_of) replaced by the leaf cparam(k)"""
+    hit = memo.get(node.id)
+    if hit is not None:
+        return hit
+    tr = node.tr
+    if node.op == "const":
+        r = tr.node("cparam", (), counter[0])
+        counter[0] += 1
+    elif node.op == "in":
+        r = node
+    else:
+        args = tuple(_template_of(a, memo, counter) for a in node.args)
+        # (no simplification: the slots must stay where they are)
+        r = tr.node(node.op, args, node.val if node.op not in ("add", "sub", "mul", "div") else None)
+    memo[node.id] = r
+    return r
+
+
+def _roll_sums(root):
+    """(rest, groups): root == rest + sum over groups of sum_i sign * body(q; table[i]).  rest is a Sym or None."""
+    terms = _flatten_sum(root)
+    by_shape, order = {}, []
+    for sg, n in terms:
+        consts = []
+        sig = _shape_of(n, {}, consts)
+        key = None if sig == "C" else sig
+        if key not in by_shape:
+            by_shape[key] = []
+            order.append(key)
+        by_shape[key].append((sg, n, consts))
+    rest_terms, groups = [], []
+    for key in order:
+        members = by_shape[key]
+        K = len(members[0][2])
+        if key is None or len(members) < ROLL_MIN_TERMS or K == 0:
+            rest_terms += [(sg, n) for sg, n, _ in members]
+            continue
+        body = _template_of(members[0][1], {}, [0])
+        # the sign rides as one more table column
+        table = np.array([list(cs) + [sg] for sg, _, cs in members], dtype=np.float64)
+        groups.append({"body": body, "K": K, "table": table})
+    tr = root.tr
+    rest = None
+    if rest_terms:
+        rest = _addn([n if sg > 0 else _unary("neg", n) for sg, n in rest_terms], tr.const(0.0))
+    return rest, groups
+
+
+def generate_source_rolled(rest, groups, D):
+    """potential / gradient source with one loop per rolled group; returns (source, params)"""
+    tr = groups[0]["body"].tr
+    zero = tr.const(0.0)
+    offsets, params, off = [], [], 0
+    for g in groups:
+        offsets.append(off)
+        params.append(g["table"].ravel())
+        off += g["table"].size
+    src = ["// generated by physicsbasedbayesianinference_amd.trace from a Python callable (sums over data rolled into loops)",
+           "template <class Q>", "PBBI_FN T potential(const Q& q, int D, const T* prm) {"]
+    lines, names = [], {}
+    if rest is not None:
+        _emit(_topo([rest]), names, lines)
+        src += lines + [f"    T s = {names[rest.id]};"]
+    else:
+        src += ["    T s = T(0);"]
+    for gi, g in enumerate(groups):
+        K, M = g["K"], g["table"].shape[0]
+        body_lines, bn = [], {}
+        _emit(_topo([g["body"]]), bn, body_lines)
+        src += [f"    for (int i = 0; i < {M}; ++i) {{", f"        const T* row = prm + {offsets[gi]} + i * {K + 1};"]
+        src += [f"        const T c{k} = row[{k}];" for k in range(K)]
+        src += ["    " + ln for ln in body_lines] + [f"        s += row[{K}] * {bn[g['body'].id]};", "    }"]
+    src += ["    return s;", "}"]
+    src += ["template <class Q, class G>", "PBBI_FN void gradient(const Q& q, G& g, int D, const T* prm) {"]
+    lines, names = [], {}
+    rest_grads = _gradient_nodes(rest, D) if rest is not None else [zero] * D
+    _emit(_topo(rest_grads), names, lines)
+    src += lines + [f"    T g{j} = {names[rest_grads[j].id]};" for j in range(D)]
+    for gi, g in enumerate(groups):
+        K, M = g["K"], g["table"].shape[0]
+        bg = _gradient_nodes(g["body"], D)
+        live = [j for j in range(D) if not _is_const(bg[j], 0.0)]
+        body_lines, bn = [], {}
+        _emit(_topo([bg[j] for j in live]), bn, body_lines)
+        src += [f"    for (int i = 0; i < {M}; ++i) {{", f"        const T* row = prm + {offsets[gi]} + i * {K + 1};"]
+        src += [f"        const T c{k} = row[{k}];" for k in range(K)] + [f"        const T sg = row[{K}];"]
+        src += ["    " + ln for ln in body_lines] + [f"        g{j} += sg * {bn[bg[j].id]};" for j in live] + ["    }"]
+    src += [f"    g[{j}] = g{j};" for j in range(D)] + ["}"]
+    return "\n".join(src) + "\n", np.concatenate(params)
 
 
 # ------------------------------------------------------------------------------------ entry point
@@ -1090,9 +1234,19 @@ def plan_potential(potential=None, D=None, gradient=None, density=None, prefer=N
                 plan = _plan_from_quadratic(poly, D)
     if plan is None:
         root = _expand_gauss(root)
-        if grads is None:
-            grads = _gradient_nodes(root, D)
-        plan = {"kind": "source", "source": generate_source(root, grads), "operations": tr.count}
+        ops = tr.count
+        rolled = None
+        if grads is None and ops >= ROLL_MIN_OPS:
+            rest, groups = _roll_sums(root)
+            if groups:
+                rolled = generate_source_rolled(rest, groups, D)
+        if rolled is not None:
+            plan = {"kind": "source", "source": rolled[0], "params": rolled[1], "operations": ops,
+                    "rolled_terms": int(_builtin_sum(len(g["table"]) for g in groups))}
+        else:
+            if grads is None:
+                grads = _gradient_nodes(root, D)
+            plan = {"kind": "source", "source": generate_source(root, grads), "operations": ops}
     plan["D"] = D
     return plan
 
@@ -1118,7 +1272,7 @@ def build_plan(plan, dtype="float64", device=None):
         return GaussianDense(mean, precision=plan["precision"], const=plan["const"], dtype=dtype, device=device,
                              symmetrize=False)
     from .custom import CustomPotential
-    pot = CustomPotential(plan["D"], plan["source"], (), dtype=dtype, device=device)
+    pot = CustomPotential(plan["D"], plan["source"], plan.get("params", ()), dtype=dtype, device=device)
     pot.traced_source = plan["source"]
     return pot
 

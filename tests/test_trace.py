@@ -208,6 +208,42 @@ def test_eight_schools_potential_traces_and_differentiates():
         assert np.allclose(g, central_diff(fn, q), rtol=2e-6, atol=2e-6)
 
 
+def _logistic_case(M, D, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.standard_normal((M, D))
+    y = (rs.uniform(size=M) < 0.5).astype(np.float64)
+    return X, y, (lambda w: jnp.sum(softplus(X @ w) - y * (X @ w)) + 0.5 * jnp.dot(w, w))
+
+
+def test_sums_over_data_are_rolled_into_loops():
+    """M observations of one shape -> one loop per shape over a table of constants (the plugin's params), not M
+    copies of straight-line code: same values and gradient as NumPy / central differences; small traces and
+    traces with a hand-written gradient stay unrolled."""
+    X, y, fn = _logistic_case(300, 7)
+    plan = jnp.plan_potential(fn, D=7)
+    assert plan["kind"] == "source" and plan["rolled_terms"] == 300
+    assert plan["source"].count("for (int i") == 4          # two shapes (y = 0, y = 1), potential and gradient
+    assert len(plan["source"]) < 32 * 1024 and plan["operations"] > 5000
+    # the table: 7 + 7 constants of the two dot products' rows ... per term, plus the sign column
+    pot = orc.pot_custom(complete_source(plan["source"]), 7, plan["params"])
+    q = np.random.RandomState(1).standard_normal((7, 6)) * 0.7
+    U, g = orc.potential(pot, q, want_grad=True)
+    ref = np.array([fn(q[:, n]) for n in range(6)])
+    assert np.allclose(U, ref, rtol=1e-13)
+    assert np.allclose(g, central_diff(fn, q), rtol=2e-6, atol=2e-6)
+    # a sum whose terms are negated / mixed with other parts of the expression
+    Xs, ys, _ = _logistic_case(90, 3, seed=5)
+    fn2 = lambda w: 2.5 - jnp.sum(jnp.tanh(Xs @ w) * (ys + 0.5)) + jnp.sum(0.5 * (Xs @ w - ys) ** 2) + jnp.exp(w[0] * w[1])   # noqa: E731
+    plan2 = jnp.plan_potential(fn2, D=3)
+    assert plan2.get("rolled_terms", 0) == 180 and plan2["source"].count("for (int i") == 6   # tanh terms; squares with y = 0 and y = 1
+    q2 = np.random.RandomState(2).standard_normal((3, 5)) * 0.5
+    U2, g2 = orc.potential(orc.pot_custom(complete_source(plan2["source"]), 3, plan2["params"]), q2, want_grad=True)
+    assert np.allclose(U2, [fn2(q2[:, n]) for n in range(5)], rtol=1e-12)
+    assert np.allclose(g2, central_diff(fn2, q2), rtol=2e-6, atol=2e-6)
+    # small traces stay straight-line code
+    assert "params" not in jnp.plan_potential(CASES["logistic_regression"][1], D=4)
+
+
 def test_generated_sources_build_for_gfx950():
     """The generated sources of the traced GPU tests compile into plugin kernels for gfx950 here, without a GPU
     (hipcc cross-compiles) -- and the built plugins travel to the GPU box in the in-tree cache, so that the -m gpu
@@ -232,6 +268,7 @@ def test_generated_sources_build_for_gfx950():
                                               np.log(1.0 - wa) - 0.5 * jnp.sum((q - b) ** 2) / sig ** 2)))
     cases.append((10, eight_schools_potential(centered=False)))
     cases.append((10, eight_schools_potential(centered=True)))
+    cases.append((16, _logistic_case(256, 16)[2]))      # a sum over 256 observations: rolled into loops
     for D, fn in cases:
         plan = jnp.plan_potential(fn, D=D, prefer="source")
         so = compile_plugin(plan["source"], "float64", D=D)
