@@ -67,6 +67,17 @@ def _shard_sizes(n_total, world):
     return [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
 
 
+def _exchange_sizes(Nl, device, world, group):
+    """the ranks' shard sizes when the caller did not say how the ensemble is split (one small all_gather)"""
+    import torch
+    if world == 1:
+        return [int(Nl)]
+    mine = torch.tensor([Nl], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    _dist().all_gather(every, mine, group=group)
+    return [int(x.item()) for x in every]
+
+
 class GatheredBlocks:
     """What an all-gather of (S, D, N_local) slabs lands in: ONE buffer `blocks` of shape
     (world, S, D, N_max) -- rank r's slabs at blocks[r] (columns past sizes[r] are padding when the split is
@@ -104,7 +115,8 @@ class GatheredBlocks:
         return out
 
 
-def gather_blocks(local_sdn, n_total=None, group=None, out=None, async_op=False, _force_collective=False):
+def gather_blocks(local_sdn, n_total=None, group=None, out=None, async_op=False, _force_collective=False,
+                  sizes=None):
     """ONE all-gather of per-rank (S, D, N_local) slabs, received in place into a (world, S, D, N_max)
     buffer (`out` reuses a caller-owned one) -> GatheredBlocks (no copy, no host synchronisation).
     `n_total`: chains of the whole ensemble, sharded by `shard_bounds` -- the shard sizes then follow
@@ -114,18 +126,15 @@ def gather_blocks(local_sdn, n_total=None, group=None, out=None, async_op=False,
     dist = _dist()
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     S, D, Nl = local_sdn.shape
-    if n_total is not None:
+    if sizes is not None:       # (the caller knows every rank's shard size already)
+        sizes = list(sizes)
+    elif n_total is not None:
         sizes = _shard_sizes(int(n_total), world)
         rank = dist.get_rank(group) if world > 1 else 0
         if sizes[rank] != Nl:
             raise ValueError(f"rank {rank} holds {Nl} chains, shard_bounds({n_total}, {rank}, {world}) says {sizes[rank]}")
-    elif world == 1:
-        sizes = [Nl]
     else:
-        mine = torch.tensor([Nl], dtype=torch.int64, device=local_sdn.device)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine, group=group)
-        sizes = [int(x.item()) for x in every]
+        sizes = _exchange_sizes(Nl, local_sdn.device, world, group)
     Nmax = max(sizes)
     send = local_sdn.contiguous()
     if Nl != Nmax:  # uneven split: the send buffer is padded to the largest shard
@@ -160,8 +169,7 @@ def gather_samples(local_sdn, group=None, _force_collective=False, n_total=None,
     if world == 1 and not _force_collective:  # (_force_collective: the one-rank RCCL test on a one-GPU box)
         return local_sdn
     S, D, Nl = local_sdn.shape
-    first = gather_blocks(local_sdn[:0], n_total, group, _force_collective=_force_collective) if n_total is None else None
-    sizes = first.sizes if first is not None else _shard_sizes(int(n_total), world)
+    sizes = _exchange_sizes(Nl, local_sdn.device, world, group) if n_total is None else _shard_sizes(int(n_total), world)
     N = sum(sizes)
     out = torch.empty((S, D, N), dtype=local_sdn.dtype, device=local_sdn.device)
     slab_bytes = max(1, D * max(sizes) * local_sdn.element_size())
@@ -171,7 +179,7 @@ def gather_samples(local_sdn, group=None, _force_collective=False, n_total=None,
         c = min(step, S - s0)
         if buf is None or buf.shape[1] != c:
             buf = torch.empty((world, c, D, max(sizes)), dtype=local_sdn.dtype, device=local_sdn.device)
-        blk = gather_blocks(local_sdn[s0:s0 + c], N, group, out=buf, _force_collective=_force_collective)
+        blk = gather_blocks(local_sdn[s0:s0 + c], None, group, out=buf, _force_collective=_force_collective, sizes=sizes)
         blk.to_sdn(out[s0:s0 + c])
     return out
 
