@@ -83,6 +83,8 @@ int new_handle(int kind, int D, int dtype, int device, pbbi_potential** out) {
     p->d_mean = p->d_prec = p->d_frag = p->d_mean_pad = p->d_big_PT = p->d_big_mu = nullptr;
     p->DP = 0;
     p->DPAD_big = 0;
+    p->DPS = 0;
+    p->d_sfrag = p->d_smean = nullptr;
     p->plugin = p->d_params = nullptr;
     p->n_params = 0;
     p->plugin_hmc_iter = nullptr; p->plugin_integrate = nullptr; p->plugin_eval = nullptr;
@@ -140,12 +142,13 @@ int route_hmc(const IterArgs& a) {
         return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths are served by the chain-per-lane "
                                                "kernels (D <= 32) and the dense kernel (D <= 128) only");
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
+    if (is_big(pot) && dense_stream_applies(a)) return dense_stream_hmc_iter(a);
     return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);
 }
 // consecutive iterations of pbbi_hmc_run that ONE route_hmc call may cover (IterArgs::fuse_*)
 int route_fused_iterations(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
-    if (is_big(pot) && pot->kind != KIND_CUSTOM) return 1;
+    if (is_big(pot) && pot->kind != KIND_CUSTOM) return dense_stream_applies(a) ? dense_stream_fused_iterations(a) : 1;
     if (pot->kind == KIND_CUSTOM) {
         // plugins (PBBI_PLUGIN_ABI >= 4) take the iterations of a run several at a time: their register
         // kernels keep the chain and its potential energy on chip, the workspace kernels unroll the call
@@ -691,6 +694,9 @@ int pbbi_potential_create_gauss_dense(int D, const double* mean, const double* p
     // D <= 128 in fp64: register-resident MFMA kernels; otherwise the streaming GEMM path
     if (rc == PBBI_OK) rc = dense_build_fragments(*out, precision, mean);
     if (rc == PBBI_OK && (*out)->DP == 0) rc = big_build(*out, precision, mean);
+    // 128 < D <= 256 in fp64: HMC iterations on the register-resident kernel with P streamed (kernels_dstream.hip);
+    // the GEMM path above keeps integrate(), the evaluations and the per-chain-length modes of the same handle
+    if (rc == PBBI_OK && (*out)->DP == 0) rc = dense_stream_build(*out, precision, mean);
     return finish_or_destroy(rc, out);
 }
 
@@ -741,7 +747,7 @@ int pbbi_potential_destroy(pbbi_potential* pot) {
     if (!pot) return PBBI_OK;
     DeviceGuard guard(pot->device);
     for (void* p : {pot->d_mean, pot->d_prec, pot->d_frag, pot->d_mean_pad, pot->d_big_PT, pot->d_big_mu,
-                    pot->d_params})
+                    pot->d_sfrag, pot->d_smean, pot->d_params})
         if (p) (void)hipFree(p);
     if (pot->plugin) (void)dlclose(pot->plugin);
     delete pot;
@@ -930,10 +936,23 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
     // (the dense path's slabs hold the PADDED rows: DP x N each)
     size_t carry_bytes = 2 * (size_t)(pot->DP ? pot->DP : pot->D) * (size_t)N * sizeof(double), sel_bytes = (size_t)N;
     bool use_carry = false;
+    // 128 < D <= 256: streamed dense kernel or GEMM path -- decided here, once, for every iteration of the run
+    // (iteration 0 reads the caller's stride, the others the slabs'; the carried formats of the two paths differ)
+    int route_hint = 0;
+    if (pot->kind != KIND_CUSTOM && is_big(pot)) {
+        IterArgs probe{};
+        probe.pot = pot; probe.method = method; probe.N = N; probe.L = L; probe.flags = flags;
+        probe.ldn_in = ldn; probe.ldn_out = N;
+        if (!dense_stream_applies(probe)) route_hint |= PBBI_ROUTE_NO_DENSE_STREAM;
+    }
     if (S >= 2 && pot->kind != KIND_CUSTOM && (is_dense(pot) || is_big(pot))) {
         IterArgs probe{};
         probe.pot = pot; probe.method = method; probe.N = N; probe.L = L; probe.flags = flags;
-        if (is_big(pot)) {  // the GEMM path keeps the x.g partial sums next to the accept bytes
+        probe.ldn_in = ldn; probe.ldn_out = N; probe.route_hint = route_hint;
+        if (is_big(pot) && dense_stream_applies(probe)) {  // the dense kernel's format: two padded slabs + a byte per chain
+            use_carry = dense_stream_carry_applies(probe);
+            carry_bytes = 2 * (size_t)pot->DPS * (size_t)N * sizeof(double);
+        } else if (is_big(pot)) {  // the GEMM path keeps the x.g partial sums next to the accept bytes
             use_carry = big_carry_applies(probe);
             big_carry_bytes(pot, N, &carry_bytes, &sel_bytes);
         } else {
@@ -966,6 +985,7 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
         a.rng = 1; a.seed = seed; a.iter = iter0 + (uint64_t)i; a.chain0 = chain0; a.kT = kT;
         a.stream = st;
         a.scratch = arena; a.scratch_bytes = arena ? need : 0; a.scratch_used = (i == 0) ? &need : nullptr;
+        a.route_hint = route_hint;
         if (use_carry) {
             a.carry = (i == 0) ? 1 : 2;
             a.carry_g = carry;
@@ -1073,6 +1093,14 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
     if (pot->kind == KIND_CUSTOM) {
         d = "user-potential plugin kernels (one chain per lane; registers up to D = 16 / 32, workspace beyond)";
         fuse = route_fused_iterations(a);
+    } else if (is_big(pot) && dense_stream_applies(a)) {
+        d = "k_dense_hmc (streamed P): register-resident MFMA kernel, 16 chains per wave, one wave per SIMD, the "
+            "precision matrix streamed through an LDS ring (rows padded to " + std::to_string(pot->DPS) + ")";
+        const bool carry = S >= 2 && dense_stream_carry_applies(a);
+        d += carry ? "; gradient carried between iterations: yes (L mat-vecs per iteration)"
+                   : "; gradient carried between iterations: no (L + 1 mat-vecs per iteration)";
+        if (!carry) a.carry = 0;
+        fuse = carry ? dense_stream_fused_iterations(a) : 1;
     } else if (is_big(pot)) {
         d = "kernels_big: one fused MFMA GEMM per leapfrog step over the whole ensemble";
         d += big_carry_applies(a) && S >= 2 ? "; gradient carried between iterations: yes (L GEMMs per iteration)"

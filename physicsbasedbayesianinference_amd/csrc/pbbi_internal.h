@@ -40,6 +40,10 @@ struct pbbi_potential {
     int (*plugin_hmc_iter)(const IterArgs*);
     int (*plugin_integrate)(const IntegrateArgs*);
     int (*plugin_eval)(const EvalArgs*, int mode);
+    // dense Gaussian, the same kernel with P streamed through the LDS (128 < D <= 256, fp64): kernels_dstream.hip
+    int DPS;           // D padded to 192 or 256 (0 = path not available)
+    void* d_sfrag;     // DPS*DPS elements: precision in the order the stream consumes it
+    void* d_smean;     // DPS elements, zero padded
 };
 
 // ---- error plumbing ---------------------------------------------------------
@@ -118,7 +122,10 @@ struct IterArgs {
     int carry;
     void* carry_g;
     uint8_t* carry_sel;
+    // routing decisions a run takes ONCE for all its iterations (pbbi_hmc_run): PBBI_ROUTE_* bits
+    int route_hint;
 };
+#define PBBI_ROUTE_NO_DENSE_STREAM 1  /* 128 < D <= 256 dense Gaussian: stay on the GEMM path (kernels_big.hip) */
 inline bool pbbi_dyn(const IterArgs& a) { return (a.flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0; }
 
 struct IntegrateArgs {
@@ -225,6 +232,12 @@ int dense_integrate(const IntegrateArgs& a);
 int dense_eval(const EvalArgs& a);
 int dense_energy(const EvalArgs& a);
 int dense_build_fragments(pbbi_potential* pot, const double* precision_host, const double* mean_host);
+// dense-precision Gaussian, 128 < D <= 256, fp64: the register-resident kernel with P streamed, kernels_dstream.hip
+int dense_stream_build(pbbi_potential* pot, const double* precision_host, const double* mean_host);
+bool dense_stream_applies(const IterArgs& a);
+bool dense_stream_carry_applies(const IterArgs& a);
+int dense_stream_fused_iterations(const IterArgs& a);
+int dense_stream_hmc_iter(const IterArgs& a);
 // dense-precision Gaussian, streaming MFMA GEMM per step (D > 128, fp64 / fp32), kernels_big.hip
 int big_hmc_iter(const IterArgs& a);
 int big_integrate(const IntegrateArgs& a);

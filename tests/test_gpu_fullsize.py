@@ -217,10 +217,13 @@ def _stress_problem(D, zero_mean):
 @pytest.mark.parametrize("compat", [True, False])
 @pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
                                               (100, False, False), (64, False, False), (24, True, True),
-                                              (96, True, False), (72, False, True)])
+                                              (96, True, False), (72, False, True),
+                                              # 128 < D <= 256: the same kernel with P streamed (kernels_dstream.hip)
+                                              (256, True, False), (256, False, True), (200, False, False),
+                                              (192, True, True), (130, False, True)])
 def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, method):
     from test_gpu_parity import gpu_hmc_iter
-    N, h, L = 333, 0.5, 4  # ragged: 333 = 2*128 + 77
+    N, h, L = 333, 0.5, 4  # ragged: 333 = 2*128 + 77 (streamed kernel: 5*64 + 13, three waves past the end)
     Pm, mu = _stress_problem(D, zero_mean)
     pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
     op = orc.pot_gauss_dense(mu, Pm, 0.25)
@@ -250,11 +253,14 @@ def test_dense_reject_branch_uploaded_draws(P, lib, D, zero_mean, mass, compat, 
 @pytest.mark.parametrize("compat", [True, False])
 @pytest.mark.parametrize("D,zero_mean,mass", [(128, True, False), (128, False, True), (100, True, True),
                                               (100, False, False), (96, False, False), (80, True, True),
-                                              (64, True, False)])
+                                              (64, True, False),
+                                              (256, True, False), (256, False, True), (200, True, True), (160, False, False)])
 def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat, method):
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     N, h, L, S, seed, chain0, iter0 = 333, 0.7, 4, 3, 11, 77, 5  # 40-67 % rejects in every case
+    if D > 128:
+        h = 0.45  # (streamed kernel, D up to 256: the same reject rates at a shorter step)
     Pm, mu = _stress_problem(D, zero_mean)
     pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
     op = orc.pot_gauss_dense(mu, Pm, 0.25)
@@ -297,7 +303,11 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
                                                      (33, False, False, False), (96, True, False, True),
                                                      (80, False, True, False), (70, True, True, True),
                                                      (32, True, False, True), (24, False, True, False),
-                                                     (7, True, True, True)])
+                                                     (7, True, True, True),
+                                                     # streamed P (kernels_dstream.hip): DPS = 256 and 192
+                                                     (256, True, False, True), (256, False, True, False),
+                                                     (200, False, True, False), (192, True, False, True),
+                                                     (129, False, False, True)])
 def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
     """pbbi_hmc_run on the dense kernel at D <= 128 (round 3: padded D and every tile size DP = 32 / 64 / 96 / 128, fused launches
     included -- rows d >= D are handled by bounded buffer descriptors, not guards) keeps the gradient of the chain's position between
@@ -308,6 +318,8 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     N, h, L, S, seed, chain0, iter0 = 1000, 0.7, 4, 7, 3, 19, 2
+    if D > 128:
+        h = 0.4
     Pm, mu = _stress_problem(D, zero_mean)
     pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
     m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None

@@ -2469,7 +2469,10 @@ def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
     assert "k_ros2_hmc" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.KDK_FMA)
     assert "double precision" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.DRAW_F64)
     assert "k_sep_hmc" in describe(P.GaussianDiag(np.zeros(64), prec=np.ones(64), const=0.0), 4096, flags=1 | lib.KDK_FMA)
-    assert "kernels_big" in describe(P.GaussianDense(None, precision=np.eye(256), const=0.0), 512)
+    d = describe(P.GaussianDense(None, precision=np.eye(256), const=0.0), 512)   # 128 < D <= 256: P streamed
+    assert "streamed P" in d and "carried between iterations: yes" in d and "up to 64" in d
+    assert "kernels_big" in describe(P.GaussianDense(None, precision=np.eye(300), const=0.0), 512)
+    assert "kernels_big" in describe(P.GaussianDense(None, precision=np.eye(256), const=0.0, dtype="float32"), 512)
     hmc = P.HMC(P.Ensemble(128, 256), 1.0, 0.1, None, potential=dense, rng="philox", verbose=False)
     assert "k_dense_hmc" in hmc.describeRun(10)
 
