@@ -487,6 +487,9 @@ __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
 // All four waves execute every acquire (no early exit: a wave past the end of the ensemble recomputes the
 // last tile with its stores masked).  Loads and stores of the state that sit between the DMA instructions
 // only make the vmcnt wait stricter than necessary (gfx9 retires vector memory operations in order).
+#ifndef PBBI_DSTREAM_ABLATE
+#define PBBI_DSTREAM_ABLATE 0   // timing experiments of tools/build_variant_dstream.sh; never in a shipped build
+#endif
 template <int NT>
 struct StreamCfg {
     static constexpr int NTP = NT / 2, HP = NTP / 2, KS = 4 * NT;
@@ -507,29 +510,40 @@ struct PRing {
     uint32_t woff;               // 1024 * wave
 };
 
+// one of the DMA instructions of chunk ci (a wave's share of a chunk: m = 0 .. DMA - 1)
 template <int NT>
-__device__ __forceinline__ void ring_issue(const PRing& r, int ci /* chunk of the mat-vec, compile-time */) {
+__device__ __forceinline__ void ring_issue_part(const PRing& r, int ci /* chunk of the mat-vec, compile-time */, int m) {
     using C = StreamCfg<NT>;
     typedef __attribute__((address_space(3))) void lds_void;
     const int slot = ci % C::RING;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.src, (lds_void*)(r.lds + slot * C::CHUNK + m * 4096), 16, r.voff,
+                                             (uint32_t)(ci * C::CHUNK + m * 4096) + r.woff, 0, 0);
+}
+template <int NT>
+__device__ __forceinline__ void ring_issue(const PRing& r, int ci) {
 #pragma unroll
-    for (int m = 0; m < C::DMA; ++m)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r.src, (lds_void*)(r.lds + slot * C::CHUNK + m * 4096), 16, r.voff,
-                                                 (uint32_t)(ci * C::CHUNK + m * 4096) + r.woff, 0, 0);
+    for (int m = 0; m < StreamCfg<NT>::DMA; ++m) ring_issue_part<NT>(r, ci, m);
 }
 
-template <int NT>
-__device__ __forceinline__ void ring_acquire(const PRing& r, int cj) {
+// INLOOP: the acquire inside a pass sits in the middle of a chunk's last K-step, BEFORE that K-step's DMA
+// instruction (if it has one) -- one DMA instruction fewer is younger than the chunk waited for.
+template <int NT, bool INLOOP>
+__device__ __forceinline__ void ring_acquire(const PRing& r) {
     using C = StreamCfg<NT>;
+    constexpr int YOUNGER = INLOOP ? C::DMA * (C::RING - 3) + (C::DMA < C::KC - 1 ? C::DMA : C::KC - 1)
+                                   : C::DMA * (C::RING - 2);
     // (not __syncthreads(): its release fence drains vmcnt to 0 -- the whole prefetch -- before the barrier.  The
     //  LDS reads of chunk j - 1 are complete (lgkmcnt 0), the DMA data of chunk j is in LDS once vmcnt says so.)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(C::DMA * (C::RING - 2)) : "memory");
-    ring_issue<NT>(r, (cj + C::RING - 1) % C::NCH);
+#if !(PBBI_DSTREAM_ABLATE & 2)  // (bit 1: no wait, no barrier -- timing experiment, wrong results)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(YOUNGER) : "memory");
+#endif
 }
 
 // The streamed form of matvec_pass: same MFMA order (bit-identical sums), fragments from the ring.  One wave per
-// SIMD has nobody to hide its LDS latency: the fragments of K-step s + 1 are requested in the MIDDLE of K-step
-// s's MFMAs (half of them issued and running, half still to come), into a second register set.
+// SIMD has nobody to hide its latencies, so each K-step is: half of its MFMAs | the requests of K-step s + 1 (A
+// fragments and mu into a second register set, and ONE of the DMA instructions that refill the slot the previous
+// chunk left) | the other half | x of K-step s + 1 from what has arrived meanwhile.  Chunk j + RING - 1 is
+// requested during the K-steps of chunk j, after acquire(j) has shown that everybody is done with chunk j - 1.
 template <int NT, int PASS, bool DRIFT, bool ZMEAN>
 __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* __restrict__ ringL,
                                                    const double* __restrict__ muG, double (&q)[4 * NT],
@@ -543,7 +557,7 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
         const int slot = (C0 + s / KC) % C::RING;
         return ringL[((slot * KC + s % KC) * HP + t2) * 64];
     };
-    ring_acquire<NT>(r, C0);
+    ring_acquire<NT, false>(r);
     v2f64 A[HP], An[HP];
 #pragma unroll
     for (int t2 = 0; t2 < HP; ++t2) A[t2] = frag_at(0, t2);
@@ -551,6 +565,8 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
     for (int t = 0; t < NTP; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
     if constexpr (DRIFT) q[0] = fma(vh[0], h, q[0]);
     double x = ZMEAN ? q[0] : q[0] - muG[0];
+    // Two gaps per K-step.  (One slot of other work behind every MFMA instead measured 5 % slower: a DMA
+    // instruction between two MFMAs costs more of the wave's issue time than one next to VALU work.)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -559,13 +575,13 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
             acc[2 * t2 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].y, x, acc[2 * t2 + 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        double xn = 0.0;
+        double mun = 0.0;
         if (s + 1 < KS) {
-            if ((s + 1) % KC == 0) ring_acquire<NT>(r, C0 + (s + 1) / KC);
+            if ((s + 1) % KC == 0) ring_acquire<NT, true>(r);
 #pragma unroll
             for (int t2 = 0; t2 < HP; ++t2) An[t2] = frag_at(s + 1, t2);
+            if constexpr (!ZMEAN) mun = muG[4 * (s + 1)];
             if constexpr (DRIFT) q[s + 1] = fma(vh[s + 1], h, q[s + 1]);
-            xn = ZMEAN ? q[s + 1] : q[s + 1] - muG[4 * (s + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -574,9 +590,13 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
             acc[2 * t2 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].y, x, acc[2 * t2 + 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // (the DMA instruction costs its wave 60+ cycles of issue: cheapest in this gap, which has no LDS reads)
+#if !(PBBI_DSTREAM_ABLATE & 1)  // (bit 0: the ring is never refilled -- timing experiment, wrong results)
+        if (s % KC < C::DMA) ring_issue_part<NT>(r, (C0 + s / KC + C::RING - 1) % C::NCH, s % KC);
+#endif
+        if (s + 1 < KS) x = ZMEAN ? q[s + 1] : q[s + 1] - mun;
 #pragma unroll
         for (int t2 = 0; t2 < HP; ++t2) A[t2] = An[t2];
-        x = xn;
     }
 }
 
@@ -734,6 +754,20 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     // decision rows kf.  Waves that share a SIMD drift apart, so one's draw and stores run under the other's
     // MFMAs; P is staged once per launch and q is never re-read while the chain keeps accepting.
     const int nfuse = FUSE ? prm.fuse_S : 1;
+    // KEEPG (streamed P, fused run, DP = 192): with one wave per SIMD nobody covers the wait for the carried
+    // gradient (8 of an iteration's 150 us at DP = 256, tools/stamp_probe_dstream.py).  Where the registers allow,
+    // the gradient at the chain's position therefore STAYS IN REGISTERS from one iteration to the next (gk: row
+    // pass 0, acc: row pass 1, xg_keep: this lane's part of x.g); only a rejected chain goes back to the slab of
+    // the position it started from.  The slabs are written as before -- they are what a later rejection (and
+    // the next launch) reads.  At DP = 256 the 128 extra live registers spill ~300 (a reload costs what the
+    // gradient load did): measured 1 % slower there, 2-10 % faster at DP = 192.
+#ifndef PBBI_DSTREAM_KEEPG
+#define PBBI_DSTREAM_KEEPG 1
+#endif
+    constexpr bool KEEPG = STREAM && FUSE && PBBI_DSTREAM_KEEPG && NT <= 12;
+    v4f64 acc[NTP];
+    [[maybe_unused]] v4f64 gk[KEEPG ? NTP : 1];
+    [[maybe_unused]] double xg_keep = 0.0;
     if constexpr (FUSE) {
         // The launch starts the run (fuse_first): no carried gradient exists yet.  g(q_0) is formed here, once,
         // and stored as slab 0 -- what a CARRY = 1 launch did -- so that the loop below has ONE shape for every
@@ -741,13 +775,18 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         // wrote (same wave, same addresses: program order).
         if (prm.fuse_first) {
             const uint32_t vg0 = (uint32_t)g * ld_g + 8u * (uint32_t)cc;
-            v4f64 acc0[NTP];
+            v4f64 (&acc0)[NTP] = acc;
             MATVEC(0, false, q, q, acc0, h);
             if (valid) {
 #pragma unroll
                 for (int t = 0; t < NTP; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) store_row(gbuf, vg0, s4g, 4 * t + r, acc0[t][r]);
+            }
+            if constexpr (KEEPG) {
+                xg_keep = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc0);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) gk[t] = acc0[t];
             }
             if constexpr (NPASS == 2) {
                 MATVEC(1, false, q, q, acc0, h);
@@ -758,12 +797,25 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
                         for (int r = 0; r < 4; ++r)
                             store_row(gbuf, vg0, s4g, 4 * (NTP + t) + r, acc0[t][r]);
                 }
+                if constexpr (KEEPG) xg_keep += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc0);
             }
             __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (KEEPG) {  // the launch continues a run: once per launch, from the chain's current slab
+            const uint32_t vg0 = (uint32_t)g * ld_g + 8u * (uint32_t)cc + (csel ? prm.carry_slab_bytes : 0u);
+#pragma unroll
+            for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gk[t][r] = load_row(gbuf, vg0, s4g, 4 * t + r);
+                    acc[t][r] = load_row(gbuf, vg0, s4g, 4 * (NTP + t) + r);
+                }
+            xg_keep = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, gk);
+            xg_keep += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
         }
     }
 #pragma nounroll
     for (int kf = 0; kf < nfuse; ++kf) {
+    STAMP(42);
     const uint64_t iter_k = prm.iter + (uint64_t)kf;
     double* const ratio_k = (FUSE && prm.ratio_out) ? prm.ratio_out + (int64_t)kf * prm.N : prm.ratio_out;
     uint8_t* const reject_k = (FUSE && prm.reject_out) ? prm.reject_out + (int64_t)kf * prm.N : prm.reject_out;
@@ -783,7 +835,6 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
 
     // ---- momentum: one Philox block per 4 rows (RNG mode) or the uploaded p_in, then q
     double vh[KS];
-    v4f64 acc[NTP];
     // rows of pass PASS of the carried gradient <-> acc (element s = 4*(PASS*NTP + t) + r, like q[s])
     auto carry_load = [&](auto pass_c) {
         constexpr int PASS = decltype(pass_c)::value;
@@ -807,7 +858,35 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     using P1 = std::integral_constant<int, 1>;
     // fused run: the first pass of the carried gradient is requested before the draw (acc is idle until
     // the draw is done, and a thousand vector instructions cover the round trip)
-    if constexpr (CARRY == 2 && FUSE) carry_load(P0{});
+    if constexpr (CARRY == 2 && FUSE && !KEEPG) carry_load(P0{});
+    double pp = 0.0;
+    if constexpr (KEEPG) {
+        // Draw, kinetic energy, v = p/m and the opening half kick in ONE pass over the rows: element s of the
+        // kept gradient is consumed the moment element s of the momentum exists, so its registers are free for
+        // the next Philox block's temporaries.  Same operations on the same values in the same order as the
+        // separate loops below.
+        const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
+        const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
+        const double ck0k = 0.5 * (h * minv);
+        const bool park = prm.p_out && !(prm.flags & PBBI_COMPAT_P_FROM_OLDQ) && valid;
+        const bool draw64 = DRAW == 2 ? (prm.flags & PBBI_DRAW_F64) != 0 : DRAW == 1;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < KS / 4; ++k) {
+            double z[4];
+            rng_normal4d(prm.seed, PBBI_STREAM_MOMENTUM, iter_k, chain, (uint32_t)((k << 2) | g), draw64, z);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int s = 4 * k + sl;
+                double pv = (FULL || 16 * k + 4 * sl + g < D) ? z[sl] * pstd : 0.0;
+                if (park) store_row(pout_k, vout, s4out, s, pv);
+                pp += pv * pv;
+                pv *= minv;
+                vh[s] = fma(-(k < NTP ? gk[k % NTP][sl] : acc[k % NTP][sl]), ck0k, pv);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // block by block: interleaved blocks keep every block's temporaries live
+        }
+        STAMP(2);
+    } else {
     if (rng) {
         const uint64_t chain = prm.chain0 + (uint64_t)(n0 + cc);
         const double pstd = sqrt(m * prm.kT);  // src/ensemble.py:88
@@ -837,13 +916,13 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         for (int s = 0; s < KS; ++s) q[s] = load_row(qin, vin, s4in, s);
     }
     __builtin_amdgcn_sched_barrier(0);
-    double pp = 0.0;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         pp += vh[s] * vh[s];
         vh[s] *= minv;  // v = p/m  (:106), as p*(1/m)
     }
     __builtin_amdgcn_sched_barrier(0);
+    }
     STAMP(3);
 
     // ---- g(q_0) in row passes: U(q_old) and the first half kick
@@ -856,13 +935,17 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
     }
     const double ck0 = (DYN && Ln == 0) ? 0.0 : ckh;  // a chain with no step gets no opening half kick either
+    double xg;
+    if constexpr (KEEPG) {  // x.g at the chain's position was kept; the half kick went with the draw
+        xg = xg_keep;
+    } else {
     if constexpr (CARRY == 2) {
         if constexpr (!FUSE) carry_load(P0{});
     } else {
         MATVEC(0, false, q, vh, acc, h);
     }
     if constexpr (CARRY == 1) carry_store(P0{}, vg_cur);
-    double xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+    xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
     kick_pass<NT, NTP, 0>(vh, acc, ck0);
     if constexpr (NPASS == 2) {
         if constexpr (CARRY == 2) carry_load(P1{});
@@ -871,9 +954,11 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
         kick_pass<NT, NTP, 1>(vh, acc, ck0);
     }
+    }
     // H(q_old, p_old) now, so that only one double stays live across the trajectory
     const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
     STAMP(4);
+    [[maybe_unused]] const double xg_old_keep = xg;
     if constexpr (!DYN) xg = 0.0;  // (DYN keeps x.g(q_0): a wave none of whose chains steps ends where it started)
     if constexpr (DYN) {
         // Per-chain lengths.  Chain c takes Ln <= L steps (drawn or uploaded) and, with PBBI_UTURN_STOP, stops
@@ -946,6 +1031,12 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         if constexpr (CARRY != 0)
             if (last) carry_store(P0{}, vg_new);  // g(q_new), for the next iteration if this one accepts
         kick_pass<NT, NTP, 0>(vh, acc, cj);
+        if constexpr (KEEPG) {
+            if (last) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) gk[t] = acc[t];
+            }
+        }
         STAMP(6 + 2 * j);
         if constexpr (NPASS == 2) {
             MATVEC(1, false, q, vh, acc, h);
@@ -1004,6 +1095,15 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         if (reject) {  // rare: fetch the old point again instead of keeping it in registers
 #pragma unroll
             for (int s = 0; s < KS; ++s) q[s] = load_row(qin_k, vin, s4in, s);  // :175
+            if constexpr (KEEPG) {  // ... and its gradient, from the slab of the position the chain started from
+#pragma unroll
+                for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gk[t][r] = load_row(gbuf, vg_cur, s4g, 4 * t + r);
+                        acc[t][r] = load_row(gbuf, vg_cur, s4g, 4 * (NTP + t) + r);
+                    }
+            }
             if (compat) {  // :176  p <- oldQ
 #pragma unroll
                 for (int s = 0; s < KS; ++s) vh[s] = q[s];
@@ -1024,6 +1124,7 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
             }
         }
         if constexpr (CARRY != 0) csel ^= reject ? 0u : 1u;  // accepted: the other slab is current now
+        if constexpr (KEEPG) xg_keep = reject ? xg_old_keep : xg;
         if (valid && g == 0) {
             if (ratio_k) ratio_k[n0 + c] = ratio;
             if (reject_k) reject_k[n0 + c] = reject ? 1 : 0;

@@ -101,6 +101,9 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     if (!dense_stream_applies(a)) return pbbi_fail(PBBI_ERR_INVALID, "streamed dense kernel: not applicable (internal)");
     if (a.N == 0) return PBBI_OK;
     DensePrm prm{};
+#ifdef PBBI_STAMPS
+    prm.stamps = g_stamp_buf;
+#endif
     prm.frag = (const double*)pot->d_sfrag;
     prm.mu = (const double*)pot->d_smean;
     prm.q_in = (const double*)a.q_in;
@@ -143,8 +146,12 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     const dim3 grid((unsigned)((a.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG)), block(BLOCK);
 #define LAUNCH_S(NT_)                                                                                            \
     {                                                                                                            \
-        if (carried) {                                                                                           \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 2, true>;                  \
+        if (carried && (a.flags & PBBI_DRAW_F64)) { /* the draw's precision at compile time: registers */       \
+            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 1, true>;                  \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                           \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
+        } else if (carried) {                                                                                    \
+            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 0, true>;                  \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else if (a.method == PBBI_LEAPFROG) {                                                                  \

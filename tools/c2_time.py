@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """C2 (d=128 dense Gaussian, 65 536 chains, fp64): microseconds per iteration of pbbi_hmc_run for the
 trajectory lengths given on the command line (default 10), after a settling run.  A/B tool:
-PBBI_NO_CARRY=1 python tools/c2_time.py 9 10 11"""
+PBBI_NO_CARRY=1 python tools/c2_time.py 9 10 11   (PBBI_TIME_D / _N / _S: another dimension, ensemble, run length)"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ import torch
 import physicsbasedbayesianinference_amd as P
 from physicsbasedbayesianinference_amd import _lib
 
-D, N, S = 128, 65536, 100
+D, N, S = (int(os.environ.get(k, v)) for k, v in (("PBBI_TIME_D", 128), ("PBBI_TIME_N", 65536), ("PBBI_TIME_S", 100)))
 A = np.random.RandomState(0).standard_normal((D, D))
 Pm = np.linalg.inv(A @ A.T / D + np.eye(D)); Pm = 0.5 * (Pm + Pm.T)
 pot = P.GaussianDense(None, precision=Pm, const=0.0)
