@@ -143,6 +143,8 @@ int pbbi_device_info(int device, pbbi_devinfo* out);
  *   gauss_dense U = 0.5*dot(x, P x) + cst, x = q-mu, grad = P x with P symmetric
  *              (= -multivariate_normal.logpdf, src/tests/test_HMC.py:49,125).
  *              `precision` is D x D row-major and MUST be symmetric.
+ *              (fp64 HMC iterations: D <= 128 on the register-resident MFMA kernel with P in LDS, 128 < D <= 256 on
+ *              the same kernel with P streamed through LDS, beyond -- and fp32 -- one fused GEMM per leapfrog step.)
  *   rosenbrock U = sum_{i<D-1} [b (q_{i+1}-q_i^2)^2 + (a-q_i)^2] / s
  *              (defined by this build).
  * mean may be NULL (= 0).
