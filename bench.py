@@ -27,7 +27,7 @@ DESIGN.md section 5); the two agree when W >= SETTLE.
 
 At N = 1 the same JSON line also carries, under "other_workloads", the lines of BASELINE configs C3
 (Rosenbrock d=32, 262 144 chains; PBBI_KDK_FMA and reference operation order), C5 (d=4096 dense,
-fp32, 8 192 chains) and of C2 through the class API's default rng="numpy" mode, measured after the headline (`--no-extras` skips them; `--workload c3|c5|
+fp32, 8 192 chains), of a dense Gaussian at d=256 (fp64, the streamed-P kernel) and of C2 through the class API's default rng="numpy" mode, measured after the headline (`--no-extras` skips them; `--workload c3|c5|
 stream|parity` prints one of them as its own line instead).
 """
 import argparse
@@ -320,8 +320,9 @@ def bench_stream(args):
 
 
 def bench_dense(args):
-    """Extra: a dense-precision Gaussian at any D (fp64): the register-resident MFMA kernel up to D = 128, the
-    GEMM path beyond.  The executed mat-vec count comes from pbbi_describe_run (carried gradient or not)."""
+    """Extra: a dense-precision Gaussian at any D (fp64): the register-resident MFMA kernel up to D = 128, the same
+    kernel with P streamed through LDS up to D = 256, the GEMM path beyond.  The executed mat-vec count comes from
+    pbbi_describe_run (carried gradient or not)."""
     import ctypes
     import torch
     import physicsbasedbayesianinference_amd as P
@@ -756,6 +757,9 @@ def main():
                              ("c3_kdk_fma", lambda: bench_c3(args, False)),
                              ("c3_exact_order", lambda: bench_c3(args, True)),
                              ("c5", lambda: bench_c5(args)),
+                             # 128 < D <= 256 (fp64): the dense kernel with P streamed through LDS (kernels_dstream.hip)
+                             ("dense_d256", lambda: bench_dense(argparse.Namespace(
+                                 dim=256, chains=args.chains, steps=args.steps, warmup=args.warmup))),
                              # the drop-in's default mode (the reference's NumPy stream, bit-exact): 30 iterations
                              ("c2_class_api_rng_numpy", lambda: bench_parity(argparse.Namespace(
                                  chains=args.chains, steps=min(args.steps, 30), warmup=3)))):

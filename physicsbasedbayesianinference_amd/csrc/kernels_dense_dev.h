@@ -437,11 +437,17 @@ constexpr int CHAINS_PER_WG2 = 128;
 // ONE set of A fragments, each pair reloaded for the next K-step right after the two MFMAs
 // that consumed it; the next x is formed in the shadow of the current K-step's MFMAs.
 // ZMEAN: mu == 0, x_s is q_s itself (no LDS read, no subtraction).  The drift is one fma.
-template <int NT, int NTP, int PASS, bool DRIFT, bool ZMEAN>
+// KSKIP (D < DP): the K-steps past the last column of P multiply zeros -- the pass ends at ks_act = ceil(D / 4)
+// (wave-uniform; the exit points that can occur for this tile size are the only ones compiled in).
+template <int NT>
+struct KSkip {  // smallest ks_act a kernel of NT row tiles is launched with: D > the next smaller tile size
+    static constexpr int MIN = NT == 2 ? 1 : NT == 4 ? 9 : NT == 6 ? 17 : NT == 8 ? 25 : NT == 12 ? 33 : NT == 16 ? 49 : 1;
+};
+template <int NT, int NTP, int PASS, bool DRIFT, bool ZMEAN, bool KSKIP = false>
 __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
                                             const double* __restrict__ muG, double (&q)[4 * NT],
                                             const double (&vh)[4 * NT], v4f64 (&acc)[NTP],
-                                            double h) {
+                                            double h, int ks_act = 4 * NT) {
     constexpr int KS = 4 * NT;
     constexpr int H = NT / 2;    // fragment pairs per K-step in the LDS image
     constexpr int HP = NTP / 2;  // pairs this pass consumes
@@ -455,6 +461,9 @@ __device__ __forceinline__ void matvec_pass(const v2f64* __restrict__ fragL,
     double x = ZMEAN ? q[0] : q[0] - muG[0];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+        if constexpr (KSKIP) {
+            if (s >= KSkip<NT>::MIN && s >= ks_act) break;
+        }
 #pragma unroll
         for (int t2 = 0; t2 < HP; ++t2) {
             acc[2 * t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].x, x, acc[2 * t2], 0, 0, 0);
@@ -544,10 +553,11 @@ __device__ __forceinline__ void ring_acquire(const PRing& r) {
 // fragments and mu into a second register set, and ONE of the DMA instructions that refill the slot the previous
 // chunk left) | the other half | x of K-step s + 1 from what has arrived meanwhile.  Chunk j + RING - 1 is
 // requested during the K-steps of chunk j, after acquire(j) has shown that everybody is done with chunk j - 1.
-template <int NT, int PASS, bool DRIFT, bool ZMEAN>
+template <int NT, int PASS, bool DRIFT, bool ZMEAN, bool KSKIP = false>
 __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* __restrict__ ringL,
                                                    const double* __restrict__ muG, double (&q)[4 * NT],
-                                                   const double (&vh)[4 * NT], v4f64 (&acc)[NT / 2], double h) {
+                                                   const double (&vh)[4 * NT], v4f64 (&acc)[NT / 2], double h,
+                                                   int ks_act = 4 * NT) {
     using C = StreamCfg<NT>;
     constexpr int KS = C::KS, HP = C::HP, NTP = C::NTP, KC = C::KC;
     constexpr int C0 = PASS * C::CPP;  // first chunk of this pass
@@ -569,6 +579,18 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
     // instruction between two MFMAs costs more of the wave's issue time than one next to VALU work.)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+        if constexpr (KSKIP) {
+            // the columns past D are zeros: no MFMAs, but the ring keeps turning (every chunk is acquired and
+            // its successor requested, in the K-steps' own order, by every wave)
+            if (s >= KSkip<NT>::MIN && s >= ks_act) {
+#pragma unroll
+                for (int s2 = s; s2 < KS; ++s2) {
+                    if (s2 + 1 < KS && (s2 + 1) % KC == 0) ring_acquire<NT, true>(r);
+                    if (s2 % KC < C::DMA) ring_issue_part<NT>(r, (C0 + s2 / KC + C::RING - 1) % C::NCH, s2 % KC);
+                }
+                break;
+            }
+        }
 #pragma unroll
         for (int t2 = 0; t2 < H1; ++t2) {
             acc[2 * t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t2].x, x, acc[2 * t2], 0, 0, 0);
@@ -707,11 +729,12 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     const double* muG = mu + g;
     const int D = prm.D;
     const double h = prm.h;
+    [[maybe_unused]] const int ks_act = (D + 3) >> 2;  // K-steps that touch a column of P (D < DP: the rest are zeros)
     // one row pass of a mat-vec: P from its LDS image, or from the ring it streams through
 #define MATVEC(PASS_, DRIFT_, Q_, V_, ACC_, H_)                                                        \
     do {                                                                                              \
-        if constexpr (STREAM) matvec_pass_stream<NT, PASS_, DRIFT_, ZMEAN>(ring, fragL, muG, Q_, V_, ACC_, H_); \
-        else matvec_pass<NT, NTP, PASS_, DRIFT_, ZMEAN>(fragL, muG, Q_, V_, ACC_, H_);                \
+        if constexpr (STREAM) matvec_pass_stream<NT, PASS_, DRIFT_, ZMEAN, !FULL>(ring, fragL, muG, Q_, V_, ACC_, H_, ks_act); \
+        else matvec_pass<NT, NTP, PASS_, DRIFT_, ZMEAN, !FULL>(fragL, muG, Q_, V_, ACC_, H_, ks_act); \
     } while (0)
 
     int64_t n0 = ((int64_t)blockIdx.x * WPB + wave) * CHAINS_PER_WAVE;  // wave-uniform
