@@ -787,7 +787,10 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
 #ifndef PBBI_DSTREAM_KEEPG
 #define PBBI_DSTREAM_KEEPG 1
 #endif
-    constexpr bool KEEPG = STREAM && FUSE && PBBI_DSTREAM_KEEPG && NT <= 12;
+#ifndef PBBI_DSTREAM_KEEPG_MAXNT
+#define PBBI_DSTREAM_KEEPG_MAXNT 12
+#endif
+    constexpr bool KEEPG = STREAM && FUSE && PBBI_DSTREAM_KEEPG && NT <= PBBI_DSTREAM_KEEPG_MAXNT;
     v4f64 acc[NTP];
     [[maybe_unused]] v4f64 gk[KEEPG ? NTP : 1];
     [[maybe_unused]] double xg_keep = 0.0;

@@ -93,6 +93,7 @@ int dense_stream_fused_iterations(const IterArgs& a) {
         return v < 1 ? 1 : v;
     }();
     if (a.carry == 0 || !a.carry_g || !a.carry_sel || !a.rng || !dense_stream_carry_applies(a)) return 1;
+    if (a.ldn_in != a.ldn_out) return 1;  // a run's first iteration reads the caller's stride: a fused launch of one
     return chunk;
 }
 

@@ -351,6 +351,43 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
     assert np.array_equal(to_numpy(qd), one[4])
 
 
+@pytest.mark.parametrize("D,N", [(256, 1), (200, 17), (256, 64), (192, 65), (140, 200)])
+def test_dense_stream_strided_state_and_small_ensembles(P, lib, D, N):
+    """kernels_dstream.hip, the corners of its launch shape: a caller's state with a leading stride > N (the run's
+    first iteration then reads another stride than it writes: a fused launch of one), ensembles of 1 chain, of less
+    than a workgroup, of exactly one and of one plus a chain (three waves past the end keep serving the ring).
+    The strided run equals the contiguous one bit for bit, both equal the oracle's replay, padding untouched."""
+    import torch
+    from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
+    h, L, S, seed, chain0, ld = 0.3, 5, 4, 8, 3, N + 9
+    Pm, mu = _stress_problem(D, False)
+    pot, op = P.GaussianDense(mu, precision=Pm, const=0.1), orc.pot_gauss_dense(mu, Pm, 0.1)
+    st = stream_ptr(0)
+    q0 = device_normal(lib, seed, lib.STREAM_POSITION, 0, chain0, D, N, 1.0) + mu[:, None]
+    out = []
+    for stride in (N, ld):
+        qd = torch.full((D, stride), 7.25, dtype=torch.float64, device="cuda")
+        qd[:, :N] = as_device(q0, 0, np.float64)
+        samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
+        reject = empty((S, N), np.uint8, 0)
+        lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), None, samples.data_ptr(), momenta.data_ptr(),
+                 reject.data_ptr(), None, N, stride, h, L, S, lib.COMPAT_P_FROM_OLDQ, seed, 0, chain0, 1.0, st)
+        torch.cuda.synchronize()
+        assert bool((qd[:, N:] == 7.25).all())
+        out.append((to_numpy(samples), to_numpy(momenta), to_numpy(reject), to_numpy(qd[:, :N].contiguous())))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    samples, momenta, reject, qf = out[0]
+    q = np.ascontiguousarray(q0)
+    for i in range(S):
+        p = device_normal(lib, seed, lib.STREAM_MOMENTUM, i, chain0, D, N, 1.0)
+        u = device_uniform(lib, seed, i, chain0, N)
+        _, rej = orc.hmc_iter(op, "Leapfrog", q, p, u, None, h, L, compat=orc.COMPAT_P_FROM_OLDQ)
+        assert np.array_equal(reject[i].astype(bool), rej)
+        assert scaled_err(samples[i], q) <= 1e-11 and scaled_err(momenta[i], p) <= 1e-11
+    assert np.array_equal(qf, samples[S - 1])
+
+
 @pytest.mark.parametrize("D,N,dtype,zero_mean,mass", [(512, 768, "float32", True, False),
                                                       (200, 150, "float64", False, True),
                                                       (384, 300, "float32", False, True)])

@@ -12,6 +12,7 @@ import torch
 import physicsbasedbayesianinference_amd as P
 from physicsbasedbayesianinference_amd import _lib
 
+METHOD = int(os.environ.get("PBBI_TIME_METHOD", 0))  # 0 Leapfrog, 1 Stormer-Verlet
 D, N, S = (int(os.environ.get(k, v)) for k, v in (("PBBI_TIME_D", 128), ("PBBI_TIME_N", 65536), ("PBBI_TIME_S", 100)))
 A = np.random.RandomState(0).standard_normal((D, D))
 Pm = np.linalg.inv(A @ A.T / D + np.eye(D)); Pm = 0.5 * (Pm + Pm.T)
@@ -23,7 +24,7 @@ rej = torch.empty((S, N), dtype=torch.uint8, device="cuda")
 
 
 def run(L, it0):
-    _lib.call("pbbi_hmc_run", pot.handle, 0, q.data_ptr(), None, samples.data_ptr(), mom.data_ptr(),
+    _lib.call("pbbi_hmc_run", pot.handle, METHOD, q.data_ptr(), None, samples.data_ptr(), mom.data_ptr(),
               rej.data_ptr(), None, N, N, 0.1, L, S, 1, 1, it0, 0, 1.0, None)
 
 
