@@ -155,7 +155,7 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
         const dim3 grid2((unsigned)tiles2), block2(BLOCK2);
         const bool zmean = pot->zero_mean;
         const bool dyn = prm.mode == 0 && (prm.flags & (PBBI_PER_CHAIN_STEPS | PBBI_UTURN_STOP)) != 0;
-        const int carry = (!dyn && prm.mode == 0 && method == PBBI_LEAPFROG && prm.carry_g) ? carry_mode : 0;
+        const int carry = (!dyn && prm.mode == 0 && prm.carry_g) ? carry_mode : 0;
 #define LAUNCH3(NT_, F_, M_, Z_)                                                                  \
     {                                                                                             \
         constexpr bool CARRYK = M_ == 0;   /* carried / fused forms exist */ \
@@ -186,6 +186,10 @@ int launch_traj(const pbbi_potential* pot, int method, const DensePrm& prm, int6
             if (int rc = set_lds(k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2>, lds)) return rc; \
             hipLaunchKernelGGL((k_dense_hmc<NTC, F_, 0, Z_, PBBI_LEAPFROG, false, 2>), grid2, block2, lds, \
                                stream, prm);                                                      \
+        } else if (method == PBBI_STORMER_VERLET && CARRYK && carry == 2) { /* always the fused form */ \
+            if (int rc = set_lds(k_dense_hmc<NTC, F_, 0, Z_, PBBI_STORMER_VERLET, false, 2, true, 2>, lds)) return rc; \
+            hipLaunchKernelGGL((k_dense_hmc<NTC, F_, 0, Z_, PBBI_STORMER_VERLET, false, 2, true, 2>), grid2, block2, \
+                               lds, stream, prm);                                                 \
         } else if (method == PBBI_LEAPFROG) {                                                     \
             if (int rc = set_lds(k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>, lds)) return rc;    \
             hipLaunchKernelGGL((k_dense_hmc<NT_, F_, M_, Z_, PBBI_LEAPFROG>), grid2, block2, lds, \
@@ -335,6 +339,18 @@ int dense_hmc_iter(const IterArgs& a) {
         prm.fuse_slab0 = a.fuse_slab0;
         prm.fuse_slab = (int64_t)a.pot->D * a.N;
         prm.fuse_q_base = (double*)a.fuse_q_base;
+    } else if (carry != 0 && a.method == PBBI_STORMER_VERLET) {
+        // carried Stormer-Verlet iterations exist in the fused form only: a call that covers one iteration is a
+        // fused launch of one (slab 0 of a base that is this call's q_out; the first iteration of a run reads
+        // the caller's state with its own stride)
+        if (!a.rng) return pbbi_fail(PBBI_ERR_INVALID, "carried dense iterations draw in the kernel (internal)");
+        prm.fuse_first = (carry == 1);
+        carry = 2;
+        prm.fuse_S = 1;
+        prm.fuse_wrap2 = 0;
+        prm.fuse_slab0 = 0;
+        prm.fuse_slab = (int64_t)a.pot->D * a.N;
+        prm.fuse_q_base = (double*)a.q_out;
     }
     return launch_traj(a.pot, a.method, prm, a.N, a.stream, carry);
 }
@@ -356,12 +372,12 @@ int dense_fused_iterations(const IterArgs& a) {
 
 // (both slabs are addressed from ONE descriptor with unsigned 32-bit byte offsets: row offset + lane offset + slab
 //  select stay below 2^32 while the two slabs together do, with a margin for the lane term)
-// May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Plain
-// Leapfrog on the two-wave kernel at D <= 128 (padded D included: DP = 32, 64, 96 or 128), both slabs -- DP rows
+// May the iterations of a run on these arguments carry the gradient (k_dense_hmc, CARRY)?  Fixed-length
+// Leapfrog / Stormer-Verlet on the two-wave kernel at D <= 128 (padded D included: DP = 32, 64, 96 or 128), both slabs -- DP rows
 // each -- addressable with 32-bit offsets.
 bool dense_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);  // A/B switch
-    return !off && a.method == PBBI_LEAPFROG && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP != 0 &&
+    return !off && (a.method == PBBI_LEAPFROG || a.method == PBBI_STORMER_VERLET) && a.L >= 1 && !pbbi_dyn(a) && a.pot->DP != 0 &&
            a.N > 0 && (uint64_t)a.pot->DP * (uint64_t)a.N * 16u < PBBI_CARRY_MAX_BYTES &&
            getenv("PBBI_DENSE_V1") == nullptr;
 }

@@ -659,7 +659,7 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 // (drift step 0, kick 0) instead of a branch around the register arrays, its last kick is its own
 // half kick, and x.g for H_new is taken at the wave's last step, where every frozen chain still
 // holds its final position.
-// CARRY (MODE 0, Leapfrog, inside pbbi_hmc_run): the last mat-vec of an iteration is g(q_new), and the
+// CARRY (MODE 0, inside pbbi_hmc_run; Stormer-Verlet in the fused form only): the last mat-vec of an iteration is g(q_new), and the
 // next iteration starts from q_new (accepted) or from the point this one started from (rejected) -- in
 // both cases a gradient that already exists.  It is kept in HBM, two slabs per chain and one byte that
 // says which is current: an iteration reads g from the current slab instead of forming it (L instead of
@@ -675,7 +675,7 @@ __device__ __forceinline__ void kick_pass(double (&vh)[4 * NT], const v4f64 (&ac
 template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, bool DYN = false, int CARRY = 0,
           bool FUSE = false, int DRAW = 2, bool STREAM = false>
 __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_dense_hmc(DensePrm prm) {
-    static_assert(CARRY == 0 || (MODE == 0 && METHOD == PBBI_LEAPFROG && !DYN), "carry: plain Leapfrog iterations");
+    static_assert(CARRY == 0 || (MODE == 0 && !DYN), "carry: HMC iterations of fixed trajectory length");
     static_assert(!FUSE || CARRY == 2, "a fused launch reads the carried gradient (its first iteration may form it)");
     static_assert(!STREAM || (!DYN && NT % 4 == 0), "streamed P: fixed trajectory lengths, two row passes");
     constexpr int DP = 16 * NT;
@@ -1076,11 +1076,18 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     if constexpr (METHOD == PBBI_STORMER_VERLET) {
         // position step L+1 (:155-159 on the last pass of the reference's loop)
         if constexpr (MODE == 0) {  // drift inside the extra mat-vec that yields U(q_new)
+            // (it is also g(q_new): carried to the next iteration exactly like Leapfrog's last mat-vec)
             MATVEC(0, true, q, vh, acc, h);
             xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+            if constexpr (CARRY != 0) carry_store(P0{}, vg_new);
+            if constexpr (KEEPG) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) gk[t] = acc[t];
+            }
             if constexpr (NPASS == 2) {
                 MATVEC(1, false, q, vh, acc, h);
                 xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+                if constexpr (CARRY != 0) carry_store(P1{}, vg_new);
             }
         } else {
 #pragma unroll

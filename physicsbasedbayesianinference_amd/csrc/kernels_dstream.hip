@@ -82,7 +82,7 @@ bool dense_stream_applies(const IterArgs& a) {
 // ... and may a run on them carry the gradient (two DPS x N slabs behind one descriptor)?
 bool dense_stream_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);
-    return !off && dense_stream_applies(a) && a.method == PBBI_LEAPFROG && a.N > 0 &&
+    return !off && dense_stream_applies(a) && a.N > 0 &&
            (uint64_t)a.pot->DPS * (uint64_t)a.N * 16u < PBBI_CARRY_MAX_BYTES;
 }
 
@@ -147,7 +147,15 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     const dim3 grid((unsigned)((a.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG)), block(BLOCK);
 #define LAUNCH_S(NT_)                                                                                            \
     {                                                                                                            \
-        if (carried && (a.flags & PBBI_DRAW_F64)) { /* the draw's precision at compile time: registers */       \
+        if (carried && a.method == PBBI_STORMER_VERLET && (a.flags & PBBI_DRAW_F64)) {                           \
+            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_STORMER_VERLET, false, 2, true, 1, true>;            \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                           \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
+        } else if (carried && a.method == PBBI_STORMER_VERLET) {                                                 \
+            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_STORMER_VERLET, false, 2, true, 0, true>;            \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                           \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
+        } else if (carried && (a.flags & PBBI_DRAW_F64)) { /* the draw's precision at compile time: registers */ \
             auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 1, true>;                  \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \

@@ -1114,7 +1114,7 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
             d += "; gradient carried between iterations: no (L + 1 mat-vecs per iteration) -- ";
             const uint64_t lim = (PBBI_CARRY_MAX_BYTES - 1) / ((uint64_t)pot->DP * 16u);
             if (S < 2) d += "a run of one iteration";
-            else if (method != PBBI_LEAPFROG || L < 1 || pbbi_dyn(a)) d += "plain Leapfrog runs with L >= 1 only";
+            else if (L < 1 || pbbi_dyn(a)) d += "runs of a fixed trajectory length L >= 1 only";
             else if ((uint64_t)N > lim)
                 d += "the two carried-gradient slabs (D*N*16 bytes) must stay below 2^32 for 32-bit buffer offsets: "
                      "at D = " + std::to_string(pot->D) + " (rows padded to " + std::to_string(pot->DP) + ") that is N <= " + std::to_string(lim) +

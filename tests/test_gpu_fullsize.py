@@ -308,7 +308,8 @@ def test_dense_reject_branch_in_kernel_draws(P, lib, D, zero_mean, mass, compat,
                                                      (256, True, False, True), (256, False, True, False),
                                                      (200, False, True, False), (192, True, False, True),
                                                      (129, False, False, True)])
-def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat):
+@pytest.mark.parametrize("method", [0, 1])   # Leapfrog, Stormer-Verlet (its extra mat-vec at q_{L+1} is g(q_new) too)
+def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, mass, compat, method):
     """pbbi_hmc_run on the dense kernel at D <= 128 (round 3: padded D and every tile size DP = 32 / 64 / 96 / 128, fused launches
     included -- rows d >= D are handled by bounded buffer descriptors, not guards) keeps the gradient of the chain's position between
     iterations (kernels_dense.hip CARRY: accepted chains take g(q_new) of the previous launch, rejected
@@ -319,7 +320,7 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     N, h, L, S, seed, chain0, iter0 = 1000, 0.7, 4, 7, 3, 19, 2
     if D > 128:
-        h = 0.4
+        h = 0.4 if method == 0 else 0.06   # (Stormer-Verlet's returned velocity is a half step behind: its energy error is first order)
     Pm, mu = _stress_problem(D, zero_mean)
     pot = P.GaussianDense(None if zero_mean else mu, precision=Pm, const=0.25)
     m = 1.0 + (np.arange(N) % 3) * 0.5 if mass else None
@@ -333,7 +334,7 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
         samples, momenta = empty((S, D, N), np.float64, 0), empty((S, D, N), np.float64, 0)
         reject, ratio = empty((S, N), np.uint8, 0), empty((S, N), np.float64, 0)
         for i in range(0, S, s_per_call):
-            lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None,
+            lib.call("pbbi_hmc_run", pot.handle, method, qd.data_ptr(), md.data_ptr() if mass else None,
                      samples[i].data_ptr(), momenta[i].data_ptr(), reject[i].data_ptr(), ratio[i].data_ptr(),
                      N, N, h, L, min(s_per_call, S - i), flags, seed, iter0 + i, chain0, 1.0, st)
         torch.cuda.synchronize()
@@ -345,7 +346,7 @@ def test_dense_run_carries_the_gradient_bit_identically(P, lib, D, zero_mean, ma
         assert np.array_equal(a, b)
     assert 0.02 < one[2].mean() < 0.8   # (rejections happen: the selector both stays and flips)
     qd = as_device(q0, 0, np.float64)   # burn-in form: nothing recorded, same final state
-    lib.call("pbbi_hmc_run", pot.handle, 0, qd.data_ptr(), md.data_ptr() if mass else None, None, None, None,
+    lib.call("pbbi_hmc_run", pot.handle, method, qd.data_ptr(), md.data_ptr() if mass else None, None, None, None,
              None, N, N, h, L, S, flags, seed, iter0, chain0, 1.0, st)
     torch.cuda.synchronize()
     assert np.array_equal(to_numpy(qd), one[4])

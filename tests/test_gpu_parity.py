@@ -2463,7 +2463,8 @@ def test_describe_run_names_the_route_and_the_carry_cliff(P, lib):
     d = describe(dense, 1 << 21)                      # past the cliff: 2 * D * N * 8 bytes would pass 2^32
     assert "carried between iterations: no" in d and "N <= 2096639 chains" in d and "shard" in d
     assert "carried between iterations: yes" in describe(dense, 2096639)
-    assert "plain Leapfrog" in describe(dense, 1000, method=1)
+    assert "carried between iterations: yes" in describe(dense, 1000, method=1)   # Stormer-Verlet carries too
+    assert "fixed trajectory length" in describe(dense, 1000, flags=1 | lib.PER_CHAIN_STEPS)
     assert "carried between iterations: yes" in describe(P.GaussianDense(None, precision=np.eye(32), const=0.0), 1000)
     assert "a run of one iteration" in describe(dense, 1000, S=1)
     assert "k_ros2_hmc" in describe(P.Rosenbrock(32), 4096, flags=1 | lib.KDK_FMA)
