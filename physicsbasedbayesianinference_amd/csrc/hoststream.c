@@ -190,6 +190,57 @@ static inline int attempt(const uint32_t* w, double* first, double* second) {
     }
 }
 
+/* The same transform over a block of attempts, in phases, so that everything except NumPy's own log() call
+ * vectorises: (a) temper + uniform -> x1, x2, r2 for every attempt, (b) compaction of the accepted ones,
+ * (c) log(r2) -- the libm call NumPy makes, scalar, bit-exactness pins it --, (d) f = sqrt(-2 log(r2) / r2) and the
+ * two products.  Division and square root are correctly rounded in every vector width and -ffp-contract=off keeps
+ * x1*x1 + x2*x2 two roundings, so the results are the bits attempt() produces (tests/test_host_logic.py:
+ * test_fast_host_stream_*).  target_clones: one build serves AVX-512, AVX2 and baseline hosts. */
+#define HS_SUB 1024
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(HS_NO_CLONES)
+#define HS_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define HS_CLONES
+#endif
+HS_CLONES static void polar_candidates(const uint32_t* restrict w, int64_t na, double* restrict x1,
+                                       double* restrict x2, double* restrict r2) {
+    for (int64_t a = 0; a < na; ++a) {
+        const double d1 = words_to_double(temper(w[4 * a]), temper(w[4 * a + 1]));
+        const double d2 = words_to_double(temper(w[4 * a + 2]), temper(w[4 * a + 3]));
+        const double a1 = 2.0 * d1 - 1.0, a2 = 2.0 * d2 - 1.0;
+        x1[a] = a1;
+        x2[a] = a2;
+        r2[a] = a1 * a1 + a2 * a2;
+    }
+}
+HS_CLONES static void polar_finish(int64_t kc, const double* restrict x1, const double* restrict x2,
+                                   const double* restrict r2, const double* restrict lg, double* restrict out) {
+    double f[HS_SUB];
+    for (int64_t k = 0; k < kc; ++k) f[k] = sqrt(-2.0 * lg[k] / r2[k]);
+    for (int64_t k = 0; k < kc; ++k) {
+        out[2 * k] = f[k] * x2[k];      /* returned first */
+        out[2 * k + 1] = f[k] * x1[k];  /* the cached one */
+    }
+}
+/* attempts a0 .. a0 + na - 1 of a chunk (na <= HS_SUB): accepted pairs appended to out / att; returns their number */
+static int64_t polar_block(const uint32_t* w, int64_t na, int64_t a0, double* out, int32_t* att) {
+    double x1[HS_SUB], x2[HS_SUB], r2[HS_SUB], lg[HS_SUB];
+    int64_t kc = 0;
+    polar_candidates(w, na, x1, x2, r2);
+    for (int64_t a = 0; a < na; ++a) {
+        const double r = r2[a];
+        if (r >= 1.0 || r == 0.0) continue;
+        x1[kc] = x1[a];
+        x2[kc] = x2[a];
+        r2[kc] = r;
+        att[kc] = (int32_t)(a0 + a);
+        ++kc;
+    }
+    for (int64_t k = 0; k < kc; ++k) lg[k] = log(r2[k]);
+    polar_finish(kc, x1, x2, r2, lg, out);
+    return kc;
+}
+
 /* waiting for another thread's result: a few pause instructions, then give the CPU away (more threads
  * than free cores must not starve the thread everybody waits for) */
 static inline void spin_pause(unsigned* spins) {
@@ -305,14 +356,10 @@ static void pass_work(hs_pass* ps, int tid) {
         const uint32_t* wc = s->blocks + w0;
         int64_t kc = 0;
         HS_T(t1);
-        for (int64_t a = 0; a < CH; ++a) {  /* transform once, into the thread's own (L2-resident) buffer */
-            double f, g;
-            if (attempt(wc + a * 4, &f, &g)) {
-                tmp[2 * kc] = f;
-                tmp[2 * kc + 1] = g;
-                att_of[kc] = (int32_t)a;
-                ++kc;
-            }
+        /* transform once, into the thread's own (L2-resident) buffer, HS_SUB attempts at a time */
+        for (int64_t a = 0; a < CH; a += HS_SUB) {
+            const int64_t na = CH - a < HS_SUB ? CH - a : HS_SUB;
+            kc += polar_block(wc + a * 4, na, a, tmp + 2 * kc, att_of + kc);
         }
         HS_T(t2);
         int64_t k = ps->acc0;

@@ -1,13 +1,27 @@
-import sys, os as _os; sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
-import numpy as np, time, os, threading
-import physicsbasedbayesianinference_amd._hoststream as hs
-n=128*65536
-for rep in range(3):
-    np.random.seed(5); t=time.perf_counter(); z=np.random.standard_normal(n); t1=time.perf_counter()-t
-    np.random.seed(5); t=time.perf_counter(); z2=hs.standard_normal(n); t2=time.perf_counter()-t
-    print("main thread: numpy %.1f ms  fast %.1f ms  equal %s" % (t1*1e3,t2*1e3,np.array_equal(z,z2)), flush=True)
-def work():
-    np.random.seed(5); t=time.perf_counter(); z2=hs.standard_normal(n); print("worker thread fast %.1f ms" % ((time.perf_counter()-t)*1e3), flush=True)
-for rep in range(2):
-    th=threading.Thread(target=work); th.start(); th.join()
-print("cpus", len(os.sched_getaffinity(0)))
+#!/usr/bin/env python3
+"""Wall time of one C2-size momentum draw (128 x 65 536 normals) through libpbbi_host.so, bit-checked against
+np.random; PBBI_HOST_LIB=<path> times another build of the library (A/B), argv = thread counts."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from physicsbasedbayesianinference_amd import _hoststream as hs
+
+if os.environ.get("PBBI_HOST_LIB"):
+    hs.LIB_PATH = os.environ["PBBI_HOST_LIB"]
+n = 128 * 65536
+np.random.seed(5)
+ref = np.random.standard_normal(n)
+for thr in [int(a) for a in sys.argv[1:]] or [1, 16]:
+    hs._load().pbbi_host_set_threads(thr)
+    times = []
+    for rep in range(7):
+        np.random.seed(5)
+        t = time.perf_counter()
+        x = hs.standard_normal(n)
+        times.append(time.perf_counter() - t)
+    print(f"{hs.LIB_PATH.split('/')[-1]} threads {thr}: best {min(times) * 1e3:.2f} ms, median {sorted(times)[3] * 1e3:.2f} ms, "
+          f"bit-exact {np.array_equal(x, ref)}", flush=True)
