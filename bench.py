@@ -352,6 +352,9 @@ def bench_dense(args):
     ks, kss = ev * 1e-3 / K, evs * 1e-3 / K
     flops_alg = flops_per_step_chain(d, L) * L * N
     flops_exec = (2.0 * d * d * ((L + 1.0 / K) if carried else L + 1) + 11.0 * d * L + 8.0 * d) * N
+    traffic = src = None
+    if d == 256 and N == 65536 and carried:  # the committed --pmc passes of tools/run_profiles_dstream.sh
+        traffic, src = profile_json("r*_pmc_dense_d256.json", "hbm_bytes_per_iteration")
     return {
         "metric": f"leapfrog-steps*chains/sec; dense Gaussian d={d}, ensemble={N}, f64",
         "value": K * L * N / t, "value_steady": K * L * N / ts, "unit": UNIT, "n_gpus": 1, "steps": K,
@@ -360,7 +363,9 @@ def bench_dense(args):
                    "accept_rate": 1.0 - float(reject[:K].float().mean().item())},
         "roofline": roofline("mfma", route.split(";")[0], FP64_MFMA_PEAK_TFLOPS, "TFLOP/s", ks, kss, flops_exec,
                              flops_alg, "the gradient mat-vecs performed (see config.route) + updates + energies, "
-                             "counted at the true D (rows padded to the kernel's tile are not work)", traffic=None)}
+                             "counted at the true D (rows padded to the kernel's tile are not work)", traffic=traffic,
+                             **({"traffic_source": src, "traffic_note": "HBM bytes per iteration (FETCH_SIZE + WRITE_SIZE, "
+                                 "separate --pmc passes); P itself is served by L2"} if src else {}))}
 
 
 def bench_gist(args):
