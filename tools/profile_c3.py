@@ -11,7 +11,7 @@ import torch
 import physicsbasedbayesianinference_amd as P
 from physicsbasedbayesianinference_amd import _lib
 
-D, N, L, S = 32, 262144, 10, 32
+D, N, L, S = int(os.environ.get("C3_D", 32)), 262144, 10, 32  # (C3_D: the multi-lane kernels at D = 64 / 128, same workload)
 FLAGS = _lib.COMPAT_P_FROM_OLDQ | (0 if os.environ.get('C3_EXACT') == '1' else _lib.KDK_FMA)
 pot = P.Rosenbrock(D)
 q = 1.0 + 0.1 * torch.randn((D, N), dtype=torch.float64, device="cuda")
