@@ -575,6 +575,7 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
     for (int t = 0; t < NTP; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
     if constexpr (DRIFT) q[0] = fma(vh[0], h, q[0]);
     double x = ZMEAN ? q[0] : q[0] - muG[0];
+    [[maybe_unused]] int s_exit = KS;  // KSKIP: the K-step at which the pass ran out of columns
     // Two gaps per K-step.  (One slot of other work behind every MFMA instead measured 5 % slower: a DMA
     // instruction between two MFMAs costs more of the wave's issue time than one next to VALU work.)
 #pragma unroll
@@ -583,11 +584,7 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
             // the columns past D are zeros: no MFMAs, but the ring keeps turning (every chunk is acquired and
             // its successor requested, in the K-steps' own order, by every wave)
             if (s >= KSkip<NT>::MIN && s >= ks_act) {
-#pragma unroll
-                for (int s2 = s; s2 < KS; ++s2) {
-                    if (s2 + 1 < KS && (s2 + 1) % KC == 0) ring_acquire<NT, true>(r);
-                    if (s2 % KC < C::DMA) ring_issue_part<NT>(r, (C0 + s2 / KC + C::RING - 1) % C::NCH, s2 % KC);
-                }
+                s_exit = s;
                 break;
             }
         }
@@ -619,6 +616,12 @@ __device__ __forceinline__ void matvec_pass_stream(const PRing& r, const v2f64* 
         if (s + 1 < KS) x = ZMEAN ? q[s + 1] : q[s + 1] - mun;
 #pragma unroll
         for (int t2 = 0; t2 < HP; ++t2) A[t2] = An[t2];
+    }
+    if constexpr (KSKIP) {  // the skipped K-steps' share of the ring protocol (a rolled loop: chunk indices at run time)
+        for (int s2 = s_exit; s2 < KS; ++s2) {
+            if (s2 + 1 < KS && (s2 + 1) % KC == 0) ring_acquire<NT, true>(r);
+            if (s2 % KC < C::DMA) ring_issue_part<NT>(r, (C0 + s2 / KC + C::RING - 1) % C::NCH, s2 % KC);
+        }
     }
 }
 

@@ -145,36 +145,43 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     }
     const size_t lds = stream_lds_bytes(pot->DPS);
     const dim3 grid((unsigned)((a.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG)), block(BLOCK);
-#define LAUNCH_S(NT_)                                                                                            \
+#define LAUNCH_S(NT_, F_)                                                                                            \
     {                                                                                                            \
         if (carried && a.method == PBBI_STORMER_VERLET && (a.flags & PBBI_DRAW_F64)) {                           \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_STORMER_VERLET, false, 2, true, 1, true>;            \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_STORMER_VERLET, false, 2, true, 1, true>;            \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else if (carried && a.method == PBBI_STORMER_VERLET) {                                                 \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_STORMER_VERLET, false, 2, true, 0, true>;            \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_STORMER_VERLET, false, 2, true, 0, true>;            \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else if (carried && (a.flags & PBBI_DRAW_F64)) { /* the draw's precision at compile time: registers */ \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 1, true>;                  \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_LEAPFROG, false, 2, true, 1, true>;                  \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else if (carried) {                                                                                    \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 2, true, 0, true>;                  \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_LEAPFROG, false, 2, true, 0, true>;                  \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else if (a.method == PBBI_LEAPFROG) {                                                                  \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, false, 0, false, 2, true>;                 \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_LEAPFROG, false, 0, false, 2, true>;                 \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         } else {                                                                                                 \
-            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_STORMER_VERLET, false, 0, false, 2, true>;           \
+            auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_STORMER_VERLET, false, 0, false, 2, true>;           \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
         }                                                                                                        \
     }
-    if (pot->DPS == 256) LAUNCH_S(16)
-    else LAUNCH_S(12)
+    // (D == DPS: no padded rows, no column skipping -- the exits cost the full tile 4 %)
+    const bool full = (pot->D == pot->DPS);
+    if (pot->DPS == 256) {
+        if (full) LAUNCH_S(16, true)
+        else LAUNCH_S(16, false)
+    } else {
+        if (full) LAUNCH_S(12, true)
+        else LAUNCH_S(12, false)
+    }
 #undef LAUNCH_S
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
