@@ -1051,9 +1051,16 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         }
         Ln = taken;
     } else {
-    for (int j = 0; j < prm.L; ++j) {
-        const bool last = (j == prm.L - 1) && METHOD == PBBI_LEAPFROG;
-        const double cj = last ? ckh : ck;  // Leapfrog: the last kick is a half kick
+    // Stormer-Verlet's position step L + 1 (:155-159 on the last pass of the reference's loop) is, for an HMC
+    // iteration, one more trip through the same body: drift + the mat-vec that yields U(q_new) -- which is also
+    // g(q_new), carried like Leapfrog's last -- and a kick with coefficient 0.  (A block of its own after the loop
+    // had the same instructions again and cost the 512-register kernels 200 spilled registers.)
+    constexpr bool SV_EXTRA = METHOD == PBBI_STORMER_VERLET && MODE == 0;
+    const int nsteps = SV_EXTRA ? prm.L + 1 : prm.L;
+    for (int j = 0; j < nsteps; ++j) {
+        const bool last = (j == nsteps - 1) && (METHOD == PBBI_LEAPFROG || SV_EXTRA);
+        // Leapfrog: the last kick is a half kick; Stormer-Verlet: every kick is a full one, the extra trip has none
+        const double cj = METHOD == PBBI_LEAPFROG ? (last ? ckh : ck) : (last ? 0.0 : ck);
         STAMP(5 + 2 * j);
         MATVEC(0, true, q, vh, acc, h);  // drift + g(q_{j+1})
         if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
@@ -1076,26 +1083,9 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         }
     }
     }
-    if constexpr (METHOD == PBBI_STORMER_VERLET) {
-        // position step L+1 (:155-159 on the last pass of the reference's loop)
-        if constexpr (MODE == 0) {  // drift inside the extra mat-vec that yields U(q_new)
-            // (it is also g(q_new): carried to the next iteration exactly like Leapfrog's last mat-vec)
-            MATVEC(0, true, q, vh, acc, h);
-            xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
-            if constexpr (CARRY != 0) carry_store(P0{}, vg_new);
-            if constexpr (KEEPG) {
+    if constexpr (METHOD == PBBI_STORMER_VERLET && MODE == 1) {  // integrate(): position step L + 1, no evaluation
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) gk[t] = acc[t];
-            }
-            if constexpr (NPASS == 2) {
-                MATVEC(1, false, q, vh, acc, h);
-                xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
-                if constexpr (CARRY != 0) carry_store(P1{}, vg_new);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) q[s] = fma(vh[s], h, q[s]);
-        }
+        for (int s = 0; s < KS; ++s) q[s] = fma(vh[s], h, q[s]);
     }
     // vh = final velocity, xg = x . g at the final position
 
