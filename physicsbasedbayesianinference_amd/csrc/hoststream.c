@@ -74,6 +74,196 @@ static void mt_next_block(const uint32_t* restrict old, uint32_t* restrict nw) {
     }
 }
 
+/* ---- MT19937 jump-ahead: several generator threads for one stream -----------------------------------------
+ * The recurrence is linear over GF(2): the state n words ahead is p_n(F) applied to the state, where F advances
+ * the 624-word window by ONE word and p_n(x) = x^n mod phi(x), phi the characteristic polynomial of F (degree
+ * 19937).  phi comes from Berlekamp-Massey on 2 x 19937 output bits, p_n from square-and-multiply, p_n(F) S
+ * from Horner's rule (19937 single-word steps, a 624-word XOR for every set coefficient: ~0.3 ms).  One table
+ * of p_{g R} (g = 1 .. generators - 1, R blocks per range) is built per range length and kept.  A jumped state
+ * has the right bits wherever the recurrence reads them -- the low 31 bits of its first word are not part of the
+ * 19937-bit state -- so it serves only as the block BEFORE a range: every word a range hands out is produced by
+ * mt_next_block itself. */
+#define MT_DEG 19937
+#define PW 312                         /* 64-bit words of a polynomial of degree < 19968 */
+
+static inline int pbit(const uint64_t* a, int i) { return (int)((a[i >> 6] >> (i & 63)) & 1u); }
+
+/* dst ^= src << sh   (src: nw words; dst holds at least nw + sh / 64 + 1 words) */
+static void pxor_shl(uint64_t* restrict dst, const uint64_t* restrict src, int nw, int sh) {
+    const int ws = sh >> 6, bs = sh & 63;
+    if (bs == 0) {
+        for (int i = 0; i < nw; ++i) dst[i + ws] ^= src[i];
+    } else {
+        for (int i = 0; i < nw; ++i) {
+            dst[i + ws] ^= src[i] << bs;
+            dst[i + ws + 1] ^= src[i] >> (64 - bs);
+        }
+    }
+}
+
+/* a (2 * PW + 2 words, degree < 2 * MT_DEG) reduced mod phi in place: degree < MT_DEG afterwards */
+static void preduce(uint64_t* a, const uint64_t* phi) {
+    for (int k = 2 * MT_DEG; k >= MT_DEG; --k)
+        if (pbit(a, k)) pxor_shl(a, phi, PW, k - MT_DEG);
+}
+
+static void pmulmod(const uint64_t* a, const uint64_t* b, const uint64_t* phi, uint64_t* out) {
+    static uint64_t acc[2 * PW + 2];   /* (called under g_busy only) */
+    memset(acc, 0, sizeof(acc));
+    for (int i = 0; i < MT_DEG; ++i)
+        if (pbit(b, i)) pxor_shl(acc, a, PW, i);
+    preduce(acc, phi);
+    memcpy(out, acc, PW * sizeof(uint64_t));
+}
+
+/* out = x^n mod phi */
+static void ppowx(uint64_t n, const uint64_t* phi, uint64_t* out) {
+    uint64_t r[PW + 1];
+    memset(r, 0, sizeof(r));
+    r[0] = 1;
+    for (int b = 63; b >= 0; --b) {
+        uint64_t t[PW];
+        memcpy(t, r, sizeof(t));
+        pmulmod(t, t, phi, r);
+        r[PW] = 0;
+        if ((n >> b) & 1u) {            /* times x */
+            for (int i = PW; i > 0; --i) r[i] = (r[i] << 1) | (r[i - 1] >> 63);
+            r[0] <<= 1;
+            if (pbit(r, MT_DEG)) for (int i = 0; i < PW; ++i) r[i] ^= phi[i];
+            r[PW] = 0;
+        }
+    }
+    memcpy(out, r, PW * sizeof(uint64_t));
+}
+
+static void mt_next_block(const uint32_t* restrict old, uint32_t* restrict nw);
+
+/* phi(x): Berlekamp-Massey over GF(2) on the lowest bit of 2 * MT_DEG + 64 consecutive state words.  The linear
+ * complexity never exceeds MT_DEG, so the connection polynomials fit PW + 2 words throughout. */
+static int mt_char_poly(uint64_t* phi) {
+    enum { NB = 2 * MT_DEG + 64, NBLK = NB / MT_N + 2, AW = PW + 2 };
+    uint32_t* blk = (uint32_t*)malloc((size_t)(NBLK + 1) * MT_N * sizeof(uint32_t));
+    uint64_t* C = (uint64_t*)calloc(4 * (size_t)AW, sizeof(uint64_t));
+    if (!blk || !C) { free(blk); free(C); return -1; }
+    uint64_t *B = C + AW, *H = B + AW, *T = H + AW;   /* H: bit i = s_{n-i} */
+    uint32_t x = 19650218u;
+    for (int i = 0; i < MT_N; ++i) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i; blk[i] = x; }
+    for (int b = 0; b < NBLK; ++b) mt_next_block(blk + (size_t)b * MT_N, blk + (size_t)(b + 1) * MT_N);
+    const uint32_t* seq = blk + MT_N;          /* generated words only */
+    C[0] = B[0] = 1;
+    int L = 0, m = 1, ok = 1;
+    for (int n = 0; n < NB && ok; ++n) {
+        for (int i = AW - 1; i > 0; --i) H[i] = (H[i] << 1) | (H[i - 1] >> 63);   /* the history moves on */
+        H[0] = (H[0] << 1) | (uint64_t)(seq[n] & 1u);
+        uint64_t par = 0;
+        const int lw = (L >> 6) + 1;
+        for (int i = 0; i < lw; ++i) par ^= C[i] & H[i];
+        if (!__builtin_parityll(par)) { ++m; continue; }
+        const int nw = AW - 1 - (m >> 6);      /* words of B that x^m B can still place inside AW words */
+        if (nw <= 0) { ok = 0; break; }
+        if (2 * L <= n) {
+            memcpy(T, C, (size_t)AW * sizeof(uint64_t));
+            pxor_shl(C, B, nw, m);
+            L = n + 1 - L;
+            memcpy(B, T, (size_t)AW * sizeof(uint64_t));
+            m = 1;
+            if (L > MT_DEG) ok = 0;
+        } else {
+            pxor_shl(C, B, nw, m);
+            ++m;
+        }
+    }
+    ok = ok && (L == MT_DEG);
+    if (ok) {   /* phi_i = c_{L-i}: the reciprocal of the connection polynomial */
+        memset(phi, 0, (size_t)PW * sizeof(uint64_t));
+        for (int i = 0; i <= MT_DEG; ++i)
+            if (pbit(C, MT_DEG - i)) phi[i >> 6] |= (uint64_t)1 << (i & 63);
+    }
+    free(blk);
+    free(C);
+    return ok ? 0 : -2;
+}
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+static void xor_block(uint32_t* restrict dst, const uint32_t* restrict src) {
+    for (int i = 0; i < MT_N; ++i) dst[i] ^= src[i];
+}
+
+/* out = the state poly(F) takes `base` to (624 words; see the note on its first word above) */
+static void mt_jump(const uint32_t* base, const uint64_t* poly, uint32_t* out) {
+    enum { CAP = 4096 };
+    uint32_t R[MT_N + CAP];             /* the window is R[h .. h + 623] (on the stack: the generator threads jump at once) */
+    int h = 0;
+    memset(R, 0, MT_N * sizeof(uint32_t));
+    for (int i = MT_DEG - 1; i >= 0; --i) {
+        const uint32_t y = (R[h] & 0x80000000u) | (R[h + 1] & 0x7fffffffu);
+        R[h + MT_N] = R[h + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        ++h;
+        if (h == CAP) { memmove(R, R + h, MT_N * sizeof(uint32_t)); h = 0; }
+        if (pbit(poly, i)) xor_block(R + h, base);
+    }
+    memcpy(out, R + h, MT_N * sizeof(uint32_t));
+}
+
+static volatile int g_busy;            /* (defined with the stream buffers below) */
+#define HS_GEN_MAX 8
+static int g_gen_threads = 2;            /* generator threads of a large draw (1 = the sequential form); measured on the
+                                          * GPU box, 16 threads, one C2 draw: 8.0 ms with 1, 7.5 with 2, 7.6-7.9 with 4-8 */
+static size_t g_gen_min_blocks = 8192;   /* ... used from this many new blocks per pass on (5 M words) */
+static size_t g_gen_round = 1024;        /* range lengths are rounded up to a multiple of this (one table per length) */
+static uint64_t g_phi[PW];
+static int g_phi_state = 0;              /* 0 not tried, 1 ready, -1 failed (sequential form from then on) */
+static uint64_t g_jump_poly[HS_GEN_MAX][PW];
+static size_t g_jump_R = 0;              /* blocks per range the table holds */
+static int g_jump_n = 0;                 /* polynomials in it (g = 1 .. g_jump_n) */
+
+void pbbi_host_debug_set_gen(int threads, int64_t min_blocks, int64_t round_blocks) {
+    g_gen_threads = threads < 1 ? 1 : (threads > HS_GEN_MAX ? HS_GEN_MAX : threads);
+    g_gen_min_blocks = min_blocks > 0 ? (size_t)min_blocks : 8192;
+    g_gen_round = round_blocks > 0 ? (size_t)round_blocks : 1024;
+}
+
+/* p_{g R} for g = 1 .. gens - 1 (under g_busy); 0 when the table is ready */
+static int jump_prepare(size_t R, int gens) {
+    if (g_phi_state == 0) g_phi_state = (mt_char_poly(g_phi) == 0) ? 1 : -1;
+    if (g_phi_state != 1) return -1;
+    if (g_jump_R == R && g_jump_n >= gens - 1) return 0;
+    ppowx((uint64_t)R * MT_N, g_phi, g_jump_poly[1]);
+    for (int g = 2; g < gens; ++g) pmulmod(g_jump_poly[g - 1], g_jump_poly[1], g_phi, g_jump_poly[g]);
+    g_jump_R = R;
+    g_jump_n = gens - 1;
+    return 0;
+}
+
+/* test hook: does a jump of `blocks` blocks land where the recurrence does?  0 = yes (every bit the recurrence
+ * reads); -1 no table; 1 mismatch.  (tests/test_host_logic.py) */
+int pbbi_host_debug_jump_check(int64_t blocks, uint32_t seed) {
+    if (blocks < 1 || blocks > 4096) return -3;
+    if (__sync_lock_test_and_set(&g_busy, 1)) return -4;
+    int rc = 0;
+    uint32_t* blk = (uint32_t*)malloc((size_t)(blocks + 1) * MT_N * sizeof(uint32_t));
+    uint32_t jumped[MT_N];
+    static uint64_t poly[PW];
+    if (!blk) rc = -1;
+    if (rc == 0 && g_phi_state == 0) g_phi_state = (mt_char_poly(g_phi) == 0) ? 1 : -1;
+    if (rc == 0 && g_phi_state != 1) rc = -1;
+    if (rc == 0) {
+        uint32_t x = seed;
+        for (int i = 0; i < MT_N; ++i) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i; blk[i] = x; }
+        for (int64_t b = 0; b < blocks; ++b) mt_next_block(blk + b * MT_N, blk + (b + 1) * MT_N);
+        ppowx((uint64_t)blocks * MT_N, g_phi, poly);
+        mt_jump(blk, poly, jumped);
+        const uint32_t* ref = blk + blocks * MT_N;
+        if ((jumped[0] ^ ref[0]) & 0x80000000u) rc = 1;
+        for (int i = 1; i < MT_N && rc == 0; ++i) if (jumped[i] != ref[i]) rc = 1;
+    }
+    free(blk);
+    __sync_lock_release(&g_busy);
+    return rc;
+}
+
 static inline uint32_t temper(uint32_t y) {
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
@@ -286,9 +476,12 @@ typedef struct {
     double last_second;            /* the variate an odd request leaves cached */
     /* the three words the threads talk through, one cache line each: the generator's progress is polled by
      * every waiting worker, and a store to a line 15 cores spin on costs a coherence round per store */
+    /* generator threads of this pass: range g = blocks [range_start[g], range_start[g + 1]); gen[g].ready = the
+     * block index range g has reached (its own cache line: every waiting worker polls it) */
+    int gens;
+    size_t range_start[HS_GEN_MAX + 1];
     char pad0[128];
-    volatile size_t blocks_ready;
-    char pad1[128 - sizeof(size_t)];
+    struct { volatile size_t ready; char pad[128 - sizeof(size_t)]; } gen[HS_GEN_MAX];
     volatile int64_t next_chunk;
     char pad2[128 - sizeof(int64_t)];
     volatile int64_t end_attempt;  /* attempt (within the pass) that supplies the last pair; -1 = none */
@@ -310,20 +503,39 @@ static double hs_prof[256][6];  /* generate, wait blocks, count, wait prefix, wr
 #define HS_ADD(slot, a, b)
 #endif
 
-static void pass_generate(hs_pass* ps) {
+/* generator thread g of a pass: range g of the blocks; g > 0 starts from a jump (see mt_jump) */
+static void pass_generate(hs_pass* ps, int g) {
     hs_stream* s = ps->s;
     HS_T(t0);
-    while (s->n_blocks < ps->blocks_target) {
+    const size_t b0 = ps->range_start[g], b1 = ps->range_start[g + 1];
+    uint32_t jumped[MT_N];
+    const uint32_t* prev = s->blocks + (b0 - 1) * MT_N;
+    if (g > 0) {
+        mt_jump(s->blocks + (ps->range_start[0] - 1) * MT_N, g_jump_poly[g], jumped);
+        prev = jumped;
+    }
+    size_t b = b0;
+    while (b < b1) {
         if (__atomic_load_n(&ps->end_attempt, __ATOMIC_RELAXED) >= 0) break;  /* the request is complete */
-        for (int b = 0; b < HS_PUBLISH_EVERY && s->n_blocks < ps->blocks_target; ++b) {
-            mt_next_block(s->blocks + (s->n_blocks - 1) * MT_N, s->blocks + s->n_blocks * MT_N);
-            ++s->n_blocks;
+        for (int k = 0; k < HS_PUBLISH_EVERY && b < b1; ++k, ++b) {
+            mt_next_block(prev, s->blocks + b * MT_N);
+            prev = s->blocks + b * MT_N;
         }
-        __atomic_store_n(&ps->blocks_ready, s->n_blocks, __ATOMIC_RELEASE);
+        __atomic_store_n(&ps->gen[g].ready, b, __ATOMIC_RELEASE);
     }
     /* whoever still waits for blocks past an early stop is released by end_attempt (checked in the wait) */
     HS_T(t1);
     HS_ADD(0, t0, t1);
+}
+
+/* are the blocks [first, need) there?  (blocks below range_start[0] come from earlier passes) */
+static inline int blocks_there(const hs_pass* ps, size_t first, size_t need) {
+    for (int g = 0; g < ps->gens; ++g) {
+        const size_t lo = ps->range_start[g], hi = ps->range_start[g + 1];
+        if (hi <= first || lo >= need) continue;
+        if (__atomic_load_n(&ps->gen[g].ready, __ATOMIC_ACQUIRE) < (need < hi ? need : hi)) return 0;
+    }
+    return 1;
 }
 
 static void pass_work(hs_pass* ps, int tid) {
@@ -345,7 +557,7 @@ static void pass_work(hs_pass* ps, int tid) {
         int skip = 0;
         unsigned spins = 0;
         HS_T(t0);
-        while (__atomic_load_n(&ps->blocks_ready, __ATOMIC_ACQUIRE) < need_blocks) {
+        while (!blocks_there(ps, w0 / MT_N, need_blocks)) {
             if (__atomic_load_n(&ps->end_attempt, __ATOMIC_ACQUIRE) >= 0) { skip = 1; break; }
             spin_pause(&spins);
         }
@@ -532,7 +744,24 @@ static int normal_core(hs_state* st, double* out, int64_t n, const double* scale
         ps.s = &s; ps.out = out; ps.scale = scale; ps.ncol = ncol; ps.n = n; ps.done = done;
         ps.pairs = pairs; ps.acc0 = acc_done; ps.att0 = att_done; ps.nch = nch; ps.CH = CH;
         ps.scratch = g_scratch;
-        ps.pref = pref; ps.blocks_ready = s.n_blocks; ps.next_chunk = 0; ps.end_attempt = -1;
+        ps.pref = pref; ps.next_chunk = 0; ps.end_attempt = -1;
+        {   /* the new blocks [n_blocks, blocks_target) in ranges, one generator thread each (a large draw only) */
+            const size_t n0 = s.n_blocks, T = ps.blocks_target > n0 ? ps.blocks_target - n0 : 0;
+            size_t R = T;
+            int gens = 1;
+            if (threads >= 4 && g_gen_threads > 1 && T >= g_gen_min_blocks) {
+                gens = g_gen_threads < threads / 2 ? g_gen_threads : threads / 2;
+                R = ((T + (size_t)gens - 1) / (size_t)gens + g_gen_round - 1) / g_gen_round * g_gen_round;
+                gens = (int)((T + R - 1) / R);
+                if (gens > 1 && jump_prepare(R, gens) != 0) gens = 1;
+            }
+            ps.gens = gens;
+            for (int g = 0; g < gens; ++g) {
+                ps.range_start[g] = n0 + (size_t)g * R;
+                ps.gen[g].ready = ps.range_start[g];
+            }
+            ps.range_start[gens] = ps.blocks_target > n0 ? ps.blocks_target : n0;
+        }
 #pragma omp parallel num_threads(threads)
         {
 #ifdef _OPENMP
@@ -541,9 +770,13 @@ static int normal_core(hs_state* st, double* out, int64_t n, const double* scale
             const int tid = 0;
 #endif
             HS_PIN_BEGIN(&node_cpus, pin);
-            if (tid == 0) pass_generate(&ps);
+            if (tid < ps.gens) pass_generate(&ps, tid);
             pass_work(&ps, tid);
             HS_PIN_END();
+        }
+        for (int g = 0; g < ps.gens; ++g) {   /* the contiguous prefix of what the generators produced */
+            s.n_blocks = ps.gen[g].ready;
+            if (ps.gen[g].ready < ps.range_start[g + 1]) break;
         }
         if (ps.end_attempt >= 0) {
             att_done += ps.end_attempt + 1;
