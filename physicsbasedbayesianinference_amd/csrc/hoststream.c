@@ -619,6 +619,7 @@ static void pass_work(hs_pass* ps, int tid) {
 #define HS_MAX_NODES 16
 static int g_nodes = -1;               /* -1 = /sys not read yet */
 static cpu_set_t g_node_cpus[HS_MAX_NODES];
+static cpu_set_t g_primary;            /* the first logical CPU of every core */
 
 static void read_nodes(void) {
     g_nodes = 0;
@@ -647,6 +648,18 @@ static void read_nodes(void) {
         g_nodes = nd + 1;
     }
     if (g_nodes < 2) g_nodes = 0;      /* one node: nothing to choose */
+    /* one logical CPU per core: the first of every SMT sibling set (two threads of a pass on one core halve both) */
+    CPU_ZERO(&g_primary);
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        char path[128], buf[64];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        FILE* f = fopen(path, "r");
+        if (!f) { if (c > 0) break; else continue; }
+        const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[got] = 0;
+        if (strtol(buf, NULL, 10) == c) CPU_SET(c, &g_primary);   /* the list starts with its lowest member */
+    }
 }
 
 /* the CPUs of the caller's node that the caller is allowed on; 0 when there is no reason to pin */
@@ -659,6 +672,11 @@ static int pass_cpus(cpu_set_t* target, int threads) {
     for (int nd = 0; nd < g_nodes; ++nd) {
         if (!CPU_ISSET(cpu, &g_node_cpus[nd])) continue;
         CPU_AND(target, &g_node_cpus[nd], &allowed);
+        {
+            cpu_set_t cores;
+            CPU_AND(&cores, target, &g_primary);
+            if (CPU_COUNT(&cores) >= threads) *target = cores;   /* enough whole cores: leave their siblings idle */
+        }
         return CPU_COUNT(target) >= threads;   /* a node with fewer usable CPUs than threads: do not squeeze */
     }
     return 0;
