@@ -19,12 +19,13 @@ lib = _lib.load()
 A = np.random.RandomState(0).standard_normal((D, D))
 Pm = np.linalg.inv(A @ A.T / D + np.eye(D)); Pm = 0.5 * (Pm + Pm.T)
 pot = P.GaussianDense(None, precision=Pm, const=0.0)
-nblk = N // 64
+WAVES = 8 if D <= 128 else 4          # (D <= 128: the resident-P kernel of kernels_dense.hip, tools/build_stamps.sh)
+nblk = N // (16 * WAVES)
 stamps = torch.zeros((nblk * 8, 64), dtype=torch.int64, device="cuda")
 lib.pbbi_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.pbbi_debug_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 q = torch.randn((D, N), dtype=torch.float64, device="cuda")
-S = 4
+S = int(os.environ.get("STAMP_ITERS", 4))
 samples = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 mom = torch.empty((S, D, N), dtype=torch.float64, device="cuda")
 rej = torch.empty((S, N), dtype=torch.uint8, device="cuda")
@@ -36,10 +37,12 @@ names = {42: "iteration top", 2: "draw done", 3: "pp, v = p/m", 4: "carried g: H
 for j in range(L):
     names[5 + 2 * j] = f"step{j} begin"; names[6 + 2 * j] = f"step{j} pass0+kick"
 order = [42, 2, 3, 4] + [k for j in range(L) for k in (5 + 2 * j, 6 + 2 * j)] + [40, 41]
-rows = [b * 8 + w for b in (0, 17, 100, 200) for w in range(4)]
-T = st[rows][:, order]
-d = np.diff(T, axis=1)
-tot = (T[:, -1] - T[:, 0]).mean()
-for i, k in enumerate(order[1:]):
-    print(f"  {names[k]:28s} {d[:, i].mean():10.0f} cyc  {100 * d[:, i].mean() / tot:5.1f} %   (min {d[:, i].min()}, max {d[:, i].max()})")
-print(f"  one iteration: {tot:.0f} s_memtime ticks (100 MHz -> {tot / 100:.1f} us)" )
+for grp in ([range(4)] if WAVES == 4 else [range(4), range(4, 8)]):
+    rows = [b * 8 + w for b in (0, 17, 100, nblk - 1) for w in grp]
+    T = st[rows][:, order]
+    d = np.diff(T, axis=1)
+    tot = (T[:, -1] - T[:, 0]).mean()
+    print(f"waves {list(grp)}")
+    for i, k in enumerate(order[1:]):
+        print(f"  {names[k]:28s} {d[:, i].mean():10.0f} cyc  {100 * d[:, i].mean() / tot:5.1f} %   (min {d[:, i].min()}, max {d[:, i].max()})")
+    print(f"  one iteration: {tot:.0f} shader cycles")
