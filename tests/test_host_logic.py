@@ -425,6 +425,21 @@ def test_fast_host_stream_jump_ahead_generators(monkeypatch):
                     got, st = hs.standard_normal(n), np.random.get_state()
                     assert np.array_equal(got, ref), (gens, threads, n)
                     assert st[0] == st_ref[0] and np.array_equal(st[1], st_ref[1]) and st[2:] == st_ref[2:]
+        # the shipped configuration on a draw large enough to use it (two generators from 8 192 new blocks on),
+        # through the scaled form Ensemble.setMomentum uses
+        lib.pbbi_host_debug_set_gen(2, 8192, 1024)
+        lib.pbbi_host_debug_set_pass(1.02, 1024, 15)
+        lib.pbbi_host_set_threads(8)
+        D, N = 24, 250000
+        scale = 1.0 + 0.25 * (np.arange(N) % 4)
+        np.random.seed(99)
+        ref, st_ref = np.random.standard_normal((D, N)) * scale, np.random.get_state()
+        np.random.seed(99)
+        out = np.empty((D, N))
+        assert hs.scaled_normal_into(out, scale) is out
+        st = np.random.get_state()
+        assert np.array_equal(out, ref)
+        assert st[0] == st_ref[0] and np.array_equal(st[1], st_ref[1]) and st[2:] == st_ref[2:]
     finally:
         lib.pbbi_host_debug_set_gen(2, 8192, 1024)
         lib.pbbi_host_debug_set_pass(1.02, 1024, 15)
