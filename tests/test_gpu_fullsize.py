@@ -642,3 +642,29 @@ def test_dense_carried_run_beyond_two_to_the_31_bytes(P, lib):
     starts = [0, N - GROUP, (1 << 20) - 8, (1 << 19) + 3, N - 128 - 5]
     replay_groups(lib, op, starts, samples, momenta, reject, qf, D, S, h, L, seed, 1.0, 0.0, True, np.float64, check)
     assert worst[0] <= 1e-11, worst[0]
+
+
+@pytest.mark.parametrize("N,carried", [((1 << 20) - 300, True), ((1 << 20) + 4001, False)])
+def test_dense_stream_beyond_two_to_the_31_bytes(P, lib, N, carried):
+    """The streamed dense kernel (D = 256) where its 32-bit byte offsets are large: one (D, N) slab is 2.1 GB, so
+    the last rows of the state arrays and slab 1 of the carried gradient sit past 2^31 (unsigned offsets: good to
+    2^32).  N just below the carried path's limit (DPS * N * 16 < 2^32 - 2^20: a fused, carried run) and just above
+    it (the same kernel family without the carry, one launch per iteration), 3 iterations against the oracle for
+    the first / last / boundary chains."""
+    import ctypes
+    D, L, h, S, seed = 256, 10, 0.1, 3, 42
+    Pm = c2_precision(D)
+    pot, op = P.GaussianDense(None, precision=Pm, const=0.0), orc.pot_gauss_dense(np.zeros(D), Pm)
+    buf = ctypes.create_string_buffer(1024)
+    lib.call("pbbi_describe_run", pot.handle, 0, N, N, L, S, 1, buf, len(buf))
+    d = buf.value.decode()
+    assert "streamed P" in d and ("carried between iterations: yes" in d) == carried, d
+    samples, momenta, reject, qf = run_as_bench(lib, pot, D, N, S, h, L, lib.COMPAT_P_FROM_OLDQ, seed, 1.0, 0.0)
+    worst = [0.0]
+
+    def check(g, i, gq, gp, grej, q, p, rej, ratio, u):
+        assert np.array_equal(grej, rej), f"group {g} iteration {i}"
+        worst[0] = max(worst[0], scaled_err(gq, q), scaled_err(gp, p))
+    starts = [0, N - GROUP, (1 << 19) + 3, N - 64 - 5, N // 64 * 64 - 8]
+    replay_groups(lib, op, starts, samples, momenta, reject, qf, D, S, h, L, seed, 1.0, 0.0, True, np.float64, check)
+    assert worst[0] <= 1e-11, worst[0]
