@@ -259,7 +259,7 @@ int pbbi_describe_run(const pbbi_potential* pot, int method, int64_t N, int64_t 
  * [0, L]; NULL = L for every chain.  steps_out (N, or (S, N) for run; may be NULL): the steps each
  * chain took.  Leapfrog only.  Served by the chain-per-lane kernels (harmonic, diagonal Gaussian,
  * Rosenbrock: fp64, D <= 32, reference operation order whatever PBBI_KDK_FMA says, bit-exact with the
- * oracle) and by the dense MFMA kernel (D <= 128, both flags: the 16-chain tile keeps stepping while
+ * oracle) and by the dense MFMA kernels (fp64, D <= 256, both flags: the 16-chain tile keeps stepping while
  * one of its chains is live; the U-turn quantity is formed from the kernel's kick-drift-kick values, so a
  * chain whose (q - q_0) . v passes zero within rounding may stop one step apart from a reference-order
  * run); with PBBI_PER_CHAIN_STEPS alone (no U-turn stop) and PBBI_KDK_FMA also by the multi-lane kernels --
@@ -284,7 +284,7 @@ int pbbi_hmc_run_dyn(const pbbi_potential* pot, int method, void* q_state, const
  * Every chain adapts its length to where it is, and the chain still leaves exp(-H) invariant: the length is a
  * Gibbs draw whose density enters the Metropolis ratio at both ends.  One iteration is three masked
  * trajectories (forward search, proposal, backward search: the per-chain-length kernels of
- * pbbi_hmc_iter_dyn, so the same potentials / sizes are served: elementwise D <= 32, dense D <= 128, other
+ * pbbi_hmc_iter_dyn, so the same potentials / sizes are served: elementwise D <= 32, dense fp64 D <= 256, other
  * handles return PBBI_ERR_UNSUPPORTED) plus an accept kernel; momenta are drawn by pbbi_philox_normal's
  * kernel for the same counters as pbbi_hmc_run (PBBI_DRAW_F64 honoured), the Metropolis uniform is the
  * chain's PBBI_STREAM_UNIFORM draw.  Arguments as pbbi_hmc_run (samples_out required); tau_out (S, 3, N)

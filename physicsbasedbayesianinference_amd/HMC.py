@@ -543,7 +543,7 @@ class HMC:
         trajectory length uniformly below that, and accepts with min(1, e^{-dH} tau_f / tau_b [L <= tau_b]), where
         tau_b is the U-turn count seen from the proposal backwards: lengths adapt to the local geometry chain by
         chain and the target stays invariant.  In-kernel draws (rng="philox" counters; draw_f64 honoured);
-        Leapfrog; potentials the per-chain-length kernels serve (elementwise D <= 32, dense D <= 128).  Returns
+        Leapfrog; potentials the per-chain-length kernels serve (elementwise D <= 32, dense fp64 D <= 256).  Returns
         (samples, momenta) like getSamples; self.gist_tau holds the (S, 3, N) counts tau_f, L, tau_b,
         self.ratios the full acceptance ratios."""
         pot, ens = self._pot, self.ensemble

@@ -680,7 +680,7 @@ template <int NT, bool FULL, int MODE, bool ZMEAN, int METHOD = PBBI_LEAPFROG, b
 __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_dense_hmc(DensePrm prm) {
     static_assert(CARRY == 0 || (MODE == 0 && !DYN), "carry: HMC iterations of fixed trajectory length");
     static_assert(!FUSE || CARRY == 2, "a fused launch reads the carried gradient (its first iteration may form it)");
-    static_assert(!STREAM || (!DYN && NT % 4 == 0), "streamed P: fixed trajectory lengths, two row passes");
+    static_assert(!STREAM || NT % 4 == 0, "streamed P: two row passes");
     constexpr int DP = 16 * NT;
     constexpr int KS = 4 * NT;
     constexpr int NPASS = (NT % 4 == 0) ? 2 : 1;  // row passes per mat-vec (NT = 6, DP = 96: one pass of six row tiles)
@@ -1024,7 +1024,17 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         using U1 = std::integral_constant<int, 1>;
         for (int j = 0; j <= prm.L; ++j) {  // at most L steps and one step that only pays a kick back
             const bool active = alive && j < Ln;
-            if (__builtin_amdgcn_ballot_w64(active || pend != 0.0) == 0) break;  // wave-uniform
+            bool more = __builtin_amdgcn_ballot_w64(active || pend != 0.0) != 0;  // wave-uniform
+            if constexpr (STREAM) {
+                // the ring keeps the workgroup's four waves in ONE mat-vec sequence: they step while any of them has a
+                // live chain (a wave whose chains are done runs frozen steps).  One flag per wave and step parity,
+                // one bare barrier per step.
+                int* vote = reinterpret_cast<int*>(mu + DP) + 4 * (j & 1);
+                if (lane == 0) vote[wave] = more ? 1 : 0;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                more = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
+            }
+            if (!more) break;
             const double cj = active ? (j == Ln - 1 ? ckh : ck) : pend;
             const double hq = active ? h : 0.0;
             pend = 0.0;

@@ -20,8 +20,8 @@
 
 namespace {
 
-inline size_t stream_lds_bytes(int DP) {
-    return DP == 256 ? (size_t)StreamCfg<16>::LDS_RING + 256 * 8 : (size_t)StreamCfg<12>::LDS_RING + 192 * 8;
+inline size_t stream_lds_bytes(int DP) {   // ring | mu | the per-chain-length kernels' step votes (2 x 4 ints)
+    return (DP == 256 ? (size_t)StreamCfg<16>::LDS_RING + 256 * 8 : (size_t)StreamCfg<12>::LDS_RING + 192 * 8) + 32;
 }
 
 template <typename K>
@@ -73,8 +73,9 @@ bool dense_stream_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_DENSE_STREAM") != nullptr);
     const pbbi_potential* pot = a.pot;
     if (off || (a.route_hint & PBBI_ROUTE_NO_DENSE_STREAM) || pot->kind != KIND_GAUSS_DENSE || pot->DPS == 0) return false;
-    if (a.L < 1 || pbbi_dyn(a)) return false;
+    if (a.L < 1) return false;
     if (a.method != PBBI_LEAPFROG && a.method != PBBI_STORMER_VERLET) return false;
+    if (pbbi_dyn(a) && a.method != PBBI_LEAPFROG) return false;   // per-chain lengths: Leapfrog (as at D <= 128)
     const int64_t ld = a.ldn_in > a.ldn_out ? a.ldn_in : a.ldn_out;
     return ld_fits(pot, ld > a.N ? ld : a.N);  // 32-bit row offsets: DPS * stride < 2^29 elements (N < 2^21 at D = 256)
 }
@@ -82,7 +83,7 @@ bool dense_stream_applies(const IterArgs& a) {
 // ... and may a run on them carry the gradient (two DPS x N slabs behind one descriptor)?
 bool dense_stream_carry_applies(const IterArgs& a) {
     static const bool off = (getenv("PBBI_NO_CARRY") != nullptr);
-    return !off && dense_stream_applies(a) && a.N > 0 &&
+    return !off && dense_stream_applies(a) && !pbbi_dyn(a) && a.N > 0 &&
            (uint64_t)a.pot->DPS * (uint64_t)a.N * 16u < PBBI_CARRY_MAX_BYTES;
 }
 
@@ -119,6 +120,8 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     prm.h = a.h; prm.cst = pot->cst; prm.kT = a.kT;
     prm.L = a.L; prm.D = pot->D; prm.flags = a.flags; prm.rng = a.rng; prm.mode = 0;
     prm.seed = a.seed; prm.iter = a.iter; prm.chain0 = a.chain0;
+    prm.steps_in = a.steps_in; prm.steps_out = a.steps_out;
+    const bool dyn = pbbi_dyn(a);
     // A carried iteration always runs in the fused kernel (one shape for a run's first and later iterations and
     // for one or many of them per launch): a call that covers one iteration is a fused launch of length 1.
     const bool carried = a.carry && a.carry_g && a.carry_sel && a.rng && dense_stream_carry_applies(a);
@@ -147,7 +150,11 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     const dim3 grid((unsigned)((a.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG)), block(BLOCK);
 #define LAUNCH_S(NT_, F_)                                                                                            \
     {                                                                                                            \
-        if (carried && a.method == PBBI_STORMER_VERLET && (a.flags & PBBI_DRAW_F64)) {                           \
+        if (dyn) { /* PBBI_PER_CHAIN_STEPS / PBBI_UTURN_STOP: the padded-rows form serves full tiles too */       \
+            auto k = k_dense_hmc<NT_, false, 0, false, PBBI_LEAPFROG, true, 0, false, 2, true>;                  \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                           \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \
+        } else if (carried && a.method == PBBI_STORMER_VERLET && (a.flags & PBBI_DRAW_F64)) {                           \
             auto k = k_dense_hmc<NT_, F_, 0, false, PBBI_STORMER_VERLET, false, 2, true, 1, true>;            \
             if (int rc = set_lds_s(k, lds)) return rc;                                                           \
             hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                              \

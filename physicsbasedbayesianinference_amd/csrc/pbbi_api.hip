@@ -138,9 +138,9 @@ int plugin_rc(int rc) {
 }
 int route_hmc(const IterArgs& a) {
     const pbbi_potential* pot = a.pot;
-    if (pbbi_dyn(a) && (pot->kind == KIND_CUSTOM || is_big(pot)))
+    if (pbbi_dyn(a) && (pot->kind == KIND_CUSTOM || (is_big(pot) && !dense_stream_applies(a))))
         return pbbi_fail(PBBI_ERR_UNSUPPORTED, "per-chain trajectory lengths are served by the chain-per-lane "
-                                               "kernels (D <= 32) and the dense kernel (D <= 128) only");
+                                               "kernels (D <= 32) and the dense kernels (fp64, D <= 256) only");
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_hmc_iter(&a)) : PBBI_OK;
     if (is_big(pot) && dense_stream_applies(a)) return dense_stream_hmc_iter(a);
     return is_big(pot) ? big_hmc_iter(a) : is_dense(pot) ? dense_hmc_iter(a) : lane_hmc_iter(a);

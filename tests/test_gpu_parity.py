@@ -1836,11 +1836,13 @@ def test_per_chain_steps_lane_kernels_bitexact(P, lib, case, mass, mode):
         assert np.array_equal(st_or, np.clip(steps_in, 0, L))
 
 
-@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False)])
+@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False),
+                                       ("dense160", True), ("dense256", False), ("dense200", True)])
 @pytest.mark.parametrize("rng", ["upload", "philox"])
 def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
     """PBBI_PER_CHAIN_STEPS on the dense MFMA kernel (finished chains frozen by per-lane coefficients, the
-    tile runs its longest chain): counts, decisions and states against the oracle."""
+    tile runs its longest chain): counts, decisions and states against the oracle.  D > 128: the streamed-P
+    kernel, whose four waves step together (a workgroup-wide vote per step keeps the ring's mat-vec sequence one)."""
     import torch
     from physicsbasedbayesianinference_amd._device import as_device, empty, stream_ptr, to_numpy
     rs = np.random.RandomState(5)
@@ -1885,7 +1887,8 @@ def test_per_chain_steps_dense_kernel(P, lib, case, mass, rng):
         assert not to_numpy(rj).astype(bool)[still].any()
 
 
-@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True), ("dense80", True)])
+@pytest.mark.parametrize("case,mass", [("dense24", False), ("dense100", True), ("dense128", False), ("dense128", True), ("dense80", True),
+                                       ("dense192", False), ("dense256", True)])
 @pytest.mark.parametrize("mode", ["uturn", "both"])
 def test_uturn_stop_dense_kernel(P, lib, case, mass, mode):
     """PBBI_UTURN_STOP on the dense MFMA kernel: a chain stops at the first step where (q - q_0) . v < 0 (the
@@ -2616,7 +2619,7 @@ def test_gist_lane_kernels_bitexact_vs_oracle(P, lib, case, mass, draw64):
     assert gtau[:, 0].min() >= 1 and (gtau[:, 1] <= gtau[:, 0]).all() and len(np.unique(gtau[:, 0])) > 3
 
 
-@pytest.mark.parametrize("D,mass", [(128, False), (100, True), (24, False)])
+@pytest.mark.parametrize("D,mass", [(128, False), (100, True), (24, False), (160, True), (256, False)])   # D > 128: streamed-P kernel
 def test_gist_dense_kernel_vs_oracle(P, lib, D, mass):
     """... and on the dense MFMA kernel (kick-drift-kick values: a U-turn dot product that passes zero within
     rounding may be seen one step apart from the oracle; such chains -- none or very few -- are left out)."""
