@@ -25,6 +25,7 @@ int main(){
     printf("alloc %.1f ms, mt blocks %.1f ms (%.2f ns/word), temper+alloc %.1f ms\n",(t1-t0)*1e3,(t2-t1)*1e3,(t2-t1)*1e9/(more*624.0),(t3-t2)*1e3);
     stream_free(&s);
   }
+  if (getenv("HS_GEN")) pbbi_host_debug_set_gen(atoi(getenv("HS_GEN")), 8192, 1024);   /* generator threads (jump-ahead) */
   int ths[]={1,2,4,8,12,16,24,32,64};
   for(int k=0;k<9;k++){
     pbbi_host_set_threads(ths[k]);
