@@ -193,3 +193,49 @@ int dense_stream_hmc_iter(const IterArgs& a) {
     PBBI_HIP(hipGetLastError());
     return PBBI_OK;
 }
+
+// integrate() (Leapfrog.integrate / StormerVerlet.integrate, src/integrator.py:105-163) on the streamed kernel: MODE 1
+// of the same template -- q, p advanced in place, Integrator.v optional.  L >= 1; the GEMM path keeps L = 0.
+bool dense_stream_integrate_applies(const IntegrateArgs& a) {
+    static const bool off = (getenv("PBBI_NO_DENSE_STREAM") != nullptr);
+    const pbbi_potential* pot = a.pot;
+    if (off || pot->kind != KIND_GAUSS_DENSE || pot->DPS == 0 || a.L < 1 || a.N < 1) return false;
+    if (a.method != PBBI_LEAPFROG && a.method != PBBI_STORMER_VERLET) return false;
+    return ld_fits(pot, a.ldn);
+}
+
+int dense_stream_integrate(const IntegrateArgs& a) {
+    const pbbi_potential* pot = a.pot;
+    if (!dense_stream_integrate_applies(a)) return pbbi_fail(PBBI_ERR_INVALID, "streamed dense integrate: not applicable (internal)");
+    DensePrm prm{};
+    prm.frag = (const double*)pot->d_sfrag;
+    prm.mu = (const double*)pot->d_smean;
+    prm.q_in = (const double*)a.q;
+    prm.p_in = (const double*)a.p;
+    prm.mass = (const double*)a.mass;
+    prm.q_out = (double*)a.q;
+    prm.p_out = (double*)a.p;
+    prm.v_out = (double*)a.v_out;
+    prm.N = a.N; prm.ldn_in = a.ldn; prm.ldn_out = a.ldn;
+    prm.h = a.h; prm.cst = pot->cst; prm.kT = 1.0;
+    prm.L = a.L; prm.D = pot->D; prm.mode = 1;
+    const size_t lds = stream_lds_bytes(pot->DPS);
+    const dim3 grid((unsigned)((a.N + CHAINS_PER_WG - 1) / CHAINS_PER_WG)), block(BLOCK);
+#define LAUNCH_I(NT_)                                                                                     \
+    {                                                                                                     \
+        if (a.method == PBBI_LEAPFROG) {                                                                  \
+            auto k = k_dense_hmc<NT_, false, 1, false, PBBI_LEAPFROG, false, 0, false, 2, true>;          \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                    \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                       \
+        } else {                                                                                          \
+            auto k = k_dense_hmc<NT_, false, 1, false, PBBI_STORMER_VERLET, false, 0, false, 2, true>;    \
+            if (int rc = set_lds_s(k, lds)) return rc;                                                    \
+            hipLaunchKernelGGL(k, grid, block, lds, a.stream, prm);                                       \
+        }                                                                                                 \
+    }
+    if (pot->DPS == 256) LAUNCH_I(16)
+    else LAUNCH_I(12)
+#undef LAUNCH_I
+    PBBI_HIP(hipGetLastError());
+    return PBBI_OK;
+}

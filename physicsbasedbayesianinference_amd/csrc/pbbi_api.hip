@@ -161,6 +161,7 @@ int route_fused_iterations(const IterArgs& a) {
 int route_integrate(const IntegrateArgs& a) {
     const pbbi_potential* pot = a.pot;
     if (pot->kind == KIND_CUSTOM) return a.N ? plugin_rc(pot->plugin_integrate(&a)) : PBBI_OK;
+    if (is_big(pot) && dense_stream_integrate_applies(a)) return dense_stream_integrate(a);
     return is_big(pot) ? big_integrate(a) : is_dense(pot) ? dense_integrate(a) : lane_integrate(a);
 }
 int route_eval(const EvalArgs& a) {

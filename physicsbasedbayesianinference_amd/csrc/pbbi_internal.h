@@ -238,6 +238,8 @@ bool dense_stream_applies(const IterArgs& a);
 bool dense_stream_carry_applies(const IterArgs& a);
 int dense_stream_fused_iterations(const IterArgs& a);
 int dense_stream_hmc_iter(const IterArgs& a);
+bool dense_stream_integrate_applies(const IntegrateArgs& a);
+int dense_stream_integrate(const IntegrateArgs& a);
 // dense-precision Gaussian, streaming MFMA GEMM per step (D > 128, fp64 / fp32), kernels_big.hip
 int big_hmc_iter(const IterArgs& a);
 int big_integrate(const IntegrateArgs& a);

@@ -540,7 +540,10 @@ def test_big_dense_asymmetric_matrix_layout(P):
 @pytest.mark.parametrize("D,mass,method,L", [(192, False, "Leapfrog", 10), (300, True, "Leapfrog", 10),
                                              (192, True, "Stormer-Verlet", 10),
                                              (260, False, "Stormer-Verlet", 0),
-                                             (200, True, "Leapfrog", 0)])
+                                             (200, True, "Leapfrog", 0),
+                                             # 128 < D <= 256, L >= 1: integrate() on the streamed-P kernel (MODE 1)
+                                             (256, True, "Leapfrog", 7), (160, False, "Stormer-Verlet", 5),
+                                             (129, True, "Stormer-Verlet", 1), (256, False, "Leapfrog", 1)])
 def test_big_dense_integrate_vs_oracle(P, D, mass, method, L):
     Pm, mu = _dense_problem(D, 3)
     N = 90
