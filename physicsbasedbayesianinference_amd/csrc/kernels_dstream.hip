@@ -12,10 +12,10 @@
 // 4.9 TB/s over the chip, all of it L2 hits (P fits every XCD's L2).  HBM sees the draw-free iteration only:
 // position in, position / momentum / carried gradient out.
 //
-// Served here: pbbi_hmc_iter / pbbi_hmc_run iterations (Leapfrog and Stormer-Verlet, fixed trajectory length),
-// with the gradient carried between the iterations of a run and up to 64 iterations per launch.  Everything
-// else at these D (integrate(), eval, energies, per-chain lengths, fp32) stays on kernels_big.hip, which is
-// built for the same handle.
+// Served here: pbbi_hmc_iter / pbbi_hmc_run iterations (Leapfrog and Stormer-Verlet) with the gradient carried
+// between the iterations of a run and up to 64 iterations per launch, per-chain trajectory lengths / the U-turn
+// stop (Leapfrog; hence GIST), and integrate() with L >= 1.  The evaluations (potential, gradient, energies),
+// L = 0 and fp32 at these D stay on kernels_big.hip, which is built for the same handle.
 #include "kernels_dense_dev.h"
 
 namespace {
