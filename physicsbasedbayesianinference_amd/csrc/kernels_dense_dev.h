@@ -964,10 +964,14 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         Ln = Ln < 0 ? 0 : (Ln > prm.L ? prm.L : Ln);
     }
     const double ck0 = (DYN && Ln == 0) ? 0.0 : ckh;  // a chain with no step gets no opening half kick either
-    double xg;
+    double xg = 0.0;
+    // FOLD1 (streamed kernels that form g(q_0) themselves, fixed lengths): the opening mat-vec is trip -1 of the step
+    // loop below -- drift step 0 (q + vh * 0 = q exactly), half kick, x.g taken for H_old -- rather than a copy of
+    // the pass code in front of it: the 512-register kernels pay for every copy of that code in spilled registers.
+    constexpr bool FOLD1 = STREAM && CARRY != 2 && !DYN;
     if constexpr (KEEPG) {  // x.g at the chain's position was kept; the half kick went with the draw
         xg = xg_keep;
-    } else {
+    } else if constexpr (!FOLD1) {
     if constexpr (CARRY == 2) {
         if constexpr (!FUSE) carry_load(P0{});
     } else {
@@ -985,7 +989,7 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     }
     }
     // H(q_old, p_old) now, so that only one double stays live across the trajectory
-    const double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
+    double oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);   // (FOLD1: set in trip -1 below)
     STAMP(4);
     [[maybe_unused]] const double xg_old_keep = xg;
     if constexpr (!DYN) xg = 0.0;  // (DYN keeps x.g(q_0): a wave none of whose chains steps ends where it started)
@@ -1067,13 +1071,17 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     // had the same instructions again and cost the 512-register kernels 200 spilled registers.)
     constexpr bool SV_EXTRA = METHOD == PBBI_STORMER_VERLET && MODE == 0;
     const int nsteps = SV_EXTRA ? prm.L + 1 : prm.L;
-    for (int j = 0; j < nsteps; ++j) {
+    for (int j = FOLD1 ? -1 : 0; j < nsteps; ++j) {
+        const bool first = FOLD1 && j < 0;
         const bool last = (j == nsteps - 1) && (METHOD == PBBI_LEAPFROG || SV_EXTRA);
         // Leapfrog: the last kick is a half kick; Stormer-Verlet: every kick is a full one, the extra trip has none
-        const double cj = METHOD == PBBI_LEAPFROG ? (last ? ckh : ck) : (last ? 0.0 : ck);
+        const double cj = first ? ck0 : (METHOD == PBBI_LEAPFROG ? (last ? ckh : ck) : (last ? 0.0 : ck));
+        const double hj = first ? 0.0 : h;
         STAMP(5 + 2 * j);
-        MATVEC(0, true, q, vh, acc, h);  // drift + g(q_{j+1})
-        if (last && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+        MATVEC(0, true, q, vh, acc, hj);  // drift + g(q_{j+1})
+        if ((first || last) && MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
+        if constexpr (CARRY == 1)
+            if (first) carry_store(P0{}, vg_cur);
         if constexpr (CARRY != 0)
             if (last) carry_store(P0{}, vg_new);  // g(q_new), for the next iteration if this one accepts
         kick_pass<NT, NTP, 0>(vh, acc, cj);
@@ -1086,10 +1094,18 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         STAMP(6 + 2 * j);
         if constexpr (NPASS == 2) {
             MATVEC(1, false, q, vh, acc, h);
-            if (last && MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+            if ((first || last) && MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
+            if constexpr (CARRY == 1)
+                if (first) carry_store(P1{}, vg_cur);
             if constexpr (CARRY != 0)
                 if (last) carry_store(P1{}, vg_new);
             kick_pass<NT, NTP, 1>(vh, acc, cj);
+        }
+        if constexpr (FOLD1) {
+            if (first) {
+                oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
+                xg = 0.0;
+            }
         }
     }
     }
