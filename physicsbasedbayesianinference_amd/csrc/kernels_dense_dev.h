@@ -968,7 +968,7 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
     // FOLD1 (streamed kernels that form g(q_0) themselves, fixed lengths): the opening mat-vec is trip -1 of the step
     // loop below -- drift step 0 (q + vh * 0 = q exactly), half kick, x.g taken for H_old -- rather than a copy of
     // the pass code in front of it: the 512-register kernels pay for every copy of that code in spilled registers.
-    constexpr bool FOLD1 = STREAM && CARRY != 2 && !DYN;
+    constexpr bool FOLD1 = STREAM && CARRY != 2;
     if constexpr (KEEPG) {  // x.g at the chain's position was kept; the half kick went with the draw
         xg = xg_keep;
     } else if constexpr (!FOLD1) {
@@ -1026,10 +1026,13 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
         };
         using U0 = std::integral_constant<int, 0>;
         using U1 = std::integral_constant<int, 1>;
-        for (int j = 0; j <= prm.L; ++j) {  // at most L steps and one step that only pays a kick back
-            const bool active = alive && j < Ln;
-            bool more = __builtin_amdgcn_ballot_w64(active || pend != 0.0) != 0;  // wave-uniform
-            if constexpr (STREAM) {
+        // (FOLD1: trip -1 is the opening mat-vec -- nobody drifts, every chain takes its opening half kick ck0, x.g is
+        //  taken for H_old, no U-turn test, no vote: all four waves make that trip)
+        for (int j = FOLD1 ? -1 : 0; j <= prm.L; ++j) {  // at most L steps and one step that only pays a kick back
+            const bool first = FOLD1 && j < 0;
+            const bool active = !first && alive && j < Ln;
+            bool more = first || __builtin_amdgcn_ballot_w64(active || pend != 0.0) != 0;  // wave-uniform
+            if (STREAM && !first) {
                 // the ring keeps the workgroup's four waves in ONE mat-vec sequence: they step while any of them has a
                 // live chain (a wave whose chains are done runs frozen steps).  One flag per wave and step parity,
                 // one bare barrier per step.
@@ -1039,19 +1042,23 @@ __global__ void __launch_bounds__(STREAM ? BLOCK : BLOCK2, STREAM ? 1 : 2) k_den
                 more = (vote[0] | vote[1] | vote[2] | vote[3]) != 0;
             }
             if (!more) break;
-            const double cj = active ? (j == Ln - 1 ? ckh : ck) : pend;
+            const double cj = first ? ck0 : (active ? (j == Ln - 1 ? ckh : ck) : pend);
             const double hq = active ? h : 0.0;
-            pend = 0.0;
+            if (!first) pend = 0.0;
             double dot = 0.0;
             MATVEC(0, true, q, vh, acc, hq);  // drift + g(q_{j+1})
             if (MODE == 0) xg = dot_pass<NT, NTP, 0, ZMEAN>(muG, q, acc);
-            if (uturn) dot = uturn_dot(U0{});
+            if (uturn && !first) dot = uturn_dot(U0{});
             kick_pass<NT, NTP, 0>(vh, acc, cj);
             if constexpr (NPASS == 2) {
                 MATVEC(1, false, q, vh, acc, h);
                 if (MODE == 0) xg += dot_pass<NT, NTP, 1, ZMEAN>(muG, q, acc);
-                if (uturn) dot += uturn_dot(U1{});
+                if (uturn && !first) dot += uturn_dot(U1{});
                 kick_pass<NT, NTP, 1>(vh, acc, cj);
+            }
+            if (first) {   // H(q_old, p_old); xg stays x.g(q_0) for a wave none of whose chains steps
+                oldH = 0.5 * chain_sum(pp) / m + (0.5 * chain_sum(xg) + prm.cst);
+                continue;
             }
             if (uturn) {
                 dot = chain_sum(dot);
